@@ -1,0 +1,180 @@
+"""Generate the parity fixtures by running the REAL reference on CPU.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+Imports /root/reference/src/model.py (torch-only module), loads the seeded synthetic weights of
+synth.py into it with load_state_dict(strict=True), and records what the reference computes:
+eval logits, train-mode (dropout=0.0) loss (plain + class-weighted, the criterion of
+src/train.py:48-50), gradients (full for the tiny cases, digests for full-width ones), three
+torch.optim.Adam steps (src/train.py:56) and the per-batch metric rule of src/train.py:260-272.
+Only tensors (inputs / expected outputs) are written - never reference source or bytecode.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REF, "src"))
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+import model as ref_model  # noqa: E402  (the reference's src/model.py)
+
+
+def ns(d):
+    return types.SimpleNamespace(**{k: (ns(v) if isinstance(v, dict) else v) for k, v in d.items()})
+
+
+def real_tables():
+    with open(os.path.join(REF, "embeddings/text_base/val.pkl"), "rb") as f:
+        t = pickle.load(f)
+    with open(os.path.join(REF, "embeddings/audio_wav2vec2/val.pkl"), "rb") as f:
+        a = pickle.load(f)
+    return t.float().contiguous(), a.float().contiguous()
+
+
+def run_case(name, out_dir, tables):
+    cfg, B, L, lengths, kind = synth.CASES[name]
+    sd = synth.make_state_dict(cfg)
+    text, audio, key_pad, emotion = synth.make_inputs(cfg, B, L, lengths, kind, real_tables=tables)
+    torch.manual_seed(0)
+    m = ref_model.M2FNet(ns(cfg))
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(m.state_dict().keys()) == list(sd.keys()), "state_dict key ORDER differs from layout.py"
+
+    rec = {}
+    if kind == "real":
+        rec["text"], rec["audio"] = text.numpy(), audio.numpy()
+
+    m.eval()
+    with torch.inference_mode():
+        rec["logits_eval"] = m(text, audio, key_pad).numpy()
+
+    # FAM layer-0 intermediates via forward hooks (MHA output, head-averaged weights, layer output)
+    if cfg["FAM"]["enabled"] and name in synth.FULL_GRAD_CASES:
+        grabbed = {}
+        h1 = m.fusion_layers[0].multihead_attention.register_forward_hook(
+            lambda mod, i, o: grabbed.update(x=o[0].detach().numpy(), w=o[1].detach().numpy()))
+        h2 = m.fusion_layers[0].register_forward_hook(lambda mod, i, o: grabbed.update(y=o.detach().numpy()))
+        with torch.no_grad():
+            m(text, audio, key_pad)
+        h1.remove(), h2.remove()
+        rec["fam0_mha_out"], rec["fam0_attn_avg"], rec["fam0_out"] = grabbed["x"], grabbed["w"], grabbed["y"]
+
+    m.train()  # dropout = 0.0 in every case -> deterministic
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)
+    crit_w = torch.nn.CrossEntropyLoss(weight=synth.CLASS_WEIGHTS, ignore_index=-1, label_smoothing=0.1)
+    out = m(text, audio, key_pad)
+    rec["logits_train"] = out.detach().numpy()
+    loss = crit(out.permute(0, 2, 1), emotion)
+    rec["loss"] = np.float64(loss.item())
+    rec["loss_weighted"] = np.float64(crit_w(out.permute(0, 2, 1), emotion).item())
+    m.zero_grad()
+    loss.backward()
+    specs_done = set()
+    norms, dots, names = [], [], []
+    for i, (k, p) in enumerate(m.state_dict(keep_vars=True).items()):
+        if id(p) in specs_done:
+            continue
+        specs_done.add(id(p))
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(k)
+        norms.append(float(g.double().norm()))
+        dots.append(float((g.double() * synth.digest_vector(tuple(g.shape), 3, i).double()).sum()))
+        if (name in synth.FULL_GRAD_CASES and g.numel() <= 32768) or g.dim() == 1 or g.numel() <= 8192:
+            rec["grad::" + k] = g.numpy().copy()
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms)
+    rec["grad_dots"] = np.array(dots)
+
+    # weighted-loss gradient digest (checks the class-weight path of the fused CE backward)
+    m.zero_grad()
+    crit_w(m(text, audio, key_pad).permute(0, 2, 1), emotion).backward()
+    rec["gradw::output_last_bias"] = list(m.parameters())[-1].grad.numpy().copy()
+    rec["gradw_norm_first"] = np.float64(float(list(m.parameters())[0].grad.double().norm()))
+
+    # three Adam steps on the same batch (coupled L2), lr large enough to be visible
+    m.load_state_dict(sd, strict=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.01)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        l = crit(m(text, audio, key_pad).permute(0, 2, 1), emotion)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    rec["adam_losses"] = np.array(losses, dtype=np.float64)
+    seen, pn, pd = set(), [], []
+    for i, (k, p) in enumerate(m.state_dict(keep_vars=True).items()):
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        pn.append(float(p.detach().double().norm()))
+        pd.append(float((p.detach().double() * synth.digest_vector(tuple(p.shape), 5, i).double()).sum()))
+        if name in synth.FULL_GRAD_CASES and p.dim() == 1:
+            rec["adam3::" + k] = p.detach().numpy().copy()
+    rec["adam3_norms"], rec["adam3_dots"] = np.array(pn), np.array(pd)
+    with torch.inference_mode():
+        m.eval()
+        rec["adam3_logits_eval"] = m(text, audio, key_pad).numpy()
+    np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **rec)
+    print(f"{name}: loss {rec['loss']:.6f} weighted {rec['loss_weighted']:.6f} "
+          f"adam {losses} -> {os.path.getsize(os.path.join(out_dir, name + '.npz')) / 1e3:.0f} kB")
+
+
+def metric_fixture(out_dir):
+    """src/train.py:260-272 rule: per-batch sklearn accuracy / weighted-F1, unweighted mean over batches."""
+    from sklearn.metrics import accuracy_score, f1_score
+    g = np.random.Generator(np.random.Philox(key=[99, 0]))
+    rec, accs, f1s = {}, [], []
+    for b, (B, L) in enumerate([(32, 16), (32, 12), (7, 9), (5, 3)]):
+        logits = g.standard_normal((B, L, 7), dtype=np.float32)
+        emo = g.integers(0, 7 if b != 3 else 3, size=(B, L)).astype(np.int64)
+        for i in range(B):
+            emo[i, int(g.integers(1, L + 1)):] = -1
+        pred = torch.argmax(torch.from_numpy(logits), dim=2).numpy()
+        msk = emo != -1
+        accs.append(accuracy_score(emo[msk], pred[msk]))
+        f1s.append(f1_score(emo[msk], pred[msk], average="weighted"))
+        rec[f"logits{b}"], rec[f"emotion{b}"] = logits, emo
+    rec["acc_per_batch"], rec["f1_per_batch"] = np.array(accs), np.array(f1s)
+    rec["acc"], rec["f1"] = np.float64(np.mean(accs)), np.float64(np.mean(f1s))
+    np.savez_compressed(os.path.join(out_dir, "metrics.npz"), **rec)
+    print("metrics:", rec["acc"], rec["f1"])
+
+
+def init_fixture(out_dir):
+    """Default-init statistics of the reference under manual_seed(0) (init parity of model.py mirrors)."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(REF, "src/config.yaml")))["model"]
+    cfg = dict(cfg, AUDIO=dict(cfg["AUDIO"], n_encoder_layers=1), TEXT=dict(cfg["TEXT"], n_encoder_layers=2),
+               FAM=dict(cfg["FAM"], n_layers=1))
+    torch.manual_seed(0)
+    m = ref_model.M2FNet(ns(cfg))
+    rec = {"names": np.array(list(m.state_dict().keys()))}
+    rec["sums"] = np.array([float(v.double().sum()) for v in m.state_dict().values()])
+    rec["abs_sums"] = np.array([float(v.double().abs().sum()) for v in m.state_dict().values()])
+    np.savez_compressed(os.path.join(out_dir, "init_seed0.npz"), **rec)
+    print("init fixture:", len(rec["names"]), "tensors")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    tabs = real_tables()
+    only = sys.argv[1:]
+    for case in synth.CASES:
+        if not only or case in only:
+            run_case(case, HERE, tabs)
+    if not only:
+        metric_fixture(HERE)
+        init_fixture(HERE)

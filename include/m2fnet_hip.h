@@ -1,0 +1,138 @@
+/* m2fnet_hip.h - C ABI of the MI355X-native M2FNet fusion-transformer training path.
+ *
+ * Shared library: multimodal-emotion-recognition_amd/csrc/libm2fnet_hip.so (gfx950 only).
+ * Plain pointers, sizes and a hipStream_t only - no torch types.  All device buffers are owned by the
+ * caller (the Python host allocates them as torch tensors; any hipMalloc'ed memory works).  Every
+ * function returns 0 on success and a non-zero code on failure (m2f_last_error() has the text); the
+ * Python binding turns non-zero into an exception.  One stream per rank, no internal threads, no
+ * allocation inside the library.
+ *
+ * The reference (iosonopersia/Multimodal-Emotion-Recognition) has no FFI: its "interface" for this path
+ * is the Python surface of src/model.py / src/train.py.  Each entry point below names the reference
+ * code it stands in for (paths relative to the reference root).
+ */
+#ifndef M2FNET_HIP_H
+#define M2FNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* m2f_stream_t;            /* hipStream_t */
+typedef struct m2f_plan m2f_plan;
+
+/* Plain-value mirror of the reference's `config.model` sub-tree (src/config.yaml:31-54, consumed at
+ * src/model.py:28-56).  dim_ff / ln_eps are the torch defaults the reference inherits (2048, 1e-5). */
+typedef struct m2f_config {
+    int32_t audio_enabled, text_enabled, fam_enabled;
+    int32_t d_audio, d_text, d_fam;
+    int32_t nhead_audio, nhead_text, nhead_fam;
+    int32_t nlayers_audio, nlayers_text, nlayers_fam;   /* n_encoder_layers, n_encoder_layers, FAM.n_layers */
+    int32_t ntrans_audio, ntrans_text;                  /* n_transformers */
+    int32_t cls_hidden, cls_out, cls_layers;
+    int32_t dim_ff;
+    float dropout;
+    float ln_eps;
+} m2f_config;
+
+enum { M2F_F32 = 0, M2F_BF16 = 1 };    /* GEMM operand precision: exact-fp32 MFMA | bf16 MFMA (fp32 accumulate) */
+
+/* Buffers inside the caller-provided workspace that the host reads / writes (m2f_plan_buffer). */
+enum {
+    M2F_BUF_TEXT = 0,       /* float [B*L, d_text]   input  (batch["text"],  src/train.py:222)          */
+    M2F_BUF_AUDIO = 1,      /* float [B*L, d_audio]  input  (batch["audio"], src/train.py:223)          */
+    M2F_BUF_KEYPAD = 2,     /* uint8 [B*L]           input  (batch["padding_mask"], 1 = pad, :225)      */
+    M2F_BUF_LABELS = 3,     /* int64 [B*L]           input  (batch["emotion"], -1 = ignore, :224)       */
+    M2F_BUF_CLASSW = 4,     /* float [16]            input  optional class weights (src/train.py:45-48) */
+    M2F_BUF_LOGITS = 5,     /* float [B*L, cls_out]  output (M2FNet.forward, src/model.py:145)          */
+    M2F_BUF_LOSS = 6,       /* float [4]: loss, denominator, numerator, -                                */
+    M2F_BUF_DLOGITS = 7,    /* float [B*L, cls_out]  d loss / d logits (written by m2f_loss, or by host) */
+    M2F_BUF_FAM0_OUT = 8,   /* float [B*L, d_fam]    first fusion layer output (kernel-level parity)     */
+    M2F_BUF_COUNT = 9
+};
+
+const char* m2f_last_error(void);
+int m2f_device_check(void);            /* 0 iff the current HIP device is gfx950 */
+
+/* Flat parameter layout = reference state_dict order (src/model.py:24-100), unique tensors
+ * only, each padded to 64 floats.  Fills offsets/numels (elements) for up to max_entries tensors and
+ * *total (flat length in elements); returns the number of unique tensors, or <0 on error. */
+int m2f_param_layout(const m2f_config* cfg, int64_t* offsets, int64_t* numels, int max_entries, int64_t* total);
+
+/* Workspace size (bytes) a plan for (cfg, B dialogues, L utterances) needs. */
+int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train);
+
+/* A plan = the launch list of one M2FNet step for fixed (cfg, B, L, precision, train/eval) bound to the
+ * caller's flat parameter buffer, flat gradient buffer (may be NULL for eval plans), workspace and
+ * dropout RNG state (4 x uint32 in device memory: seed_lo, seed_hi, step_lo, step_hi). */
+m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, int train,
+                          float* params, float* grads, void* workspace, int64_t workspace_bytes,
+                          uint32_t* rng_state);
+void m2f_plan_destroy(m2f_plan* plan);
+void* m2f_plan_buffer(m2f_plan* plan, int which);
+int m2f_plan_num_launches(m2f_plan* plan, int phase);   /* 0 fwd, 1 loss, 2 bwd */
+
+/* M2FNet.forward (src/model.py:102-145): inputs read from M2F_BUF_TEXT/AUDIO/KEYPAD, logits -> M2F_BUF_LOGITS. */
+int m2f_forward(m2f_plan* plan, m2f_stream_t stream);
+/* criterion(outputs.permute(0,2,1), emotion) (src/train.py:229; CrossEntropyLoss(ignore_index=-1,
+ * label_smoothing) of :48-50): labels from M2F_BUF_LABELS, loss -> M2F_BUF_LOSS, dlogits -> M2F_BUF_DLOGITS.
+ * normalise=1: gradient of the mean-over-valid loss; 0: gradient of the SUM (data-parallel path divides
+ * by the global denominator after the all-reduce). */
+int m2f_loss(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream);
+/* loss.backward() (src/train.py:230): consumes M2F_BUF_DLOGITS, OVERWRITES the flat gradient buffer. */
+int m2f_backward(m2f_plan* plan, m2f_stream_t stream);
+/* Fused train-step body of src/train.py:228-230 (forward + criterion + backward) with the dropout RNG
+ * advanced on the device; use_graph=1 captures the launch list into a hipGraph once and replays it. */
+int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, int use_graph,
+             m2f_stream_t stream);
+
+/* Advances the dropout RNG state by one step on the device (what nn.Dropout's generator advance is to the
+ * reference; m2f_step does it itself). */
+int m2f_rng_advance(uint32_t* rng_state, m2f_stream_t stream);
+
+/* optimizer.step() of torch.optim.Adam(lr, weight_decay) (src/train.py:56,231): coupled L2, bias-corrected,
+ * over flat buffers of n floats (n % 4 == 0).  grad_scale_ptr (device, nullable): g <- g / *grad_scale_ptr. */
+int m2f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  const float* grad_scale_ptr, m2f_stream_t stream);
+
+/* ---- kernel-level entry points (used by the parity tests; same kernels the plan launches) ---------- */
+/* C[M,N] = epilogue(A x B); layout 0: C = A[M,K] B[N,K]^T (nn.Linear forward), 1: C = A[M,K] B[K,N]
+ * (input gradient), 2: C = A[K,M]^T B[K,N] (weight gradient; bias_grad[M] = column sums of A).
+ * Optional second operand segment (a1/b1, k1) = never-materialised torch.cat along the reduction dim. */
+int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1,
+             const float* a0, int lda0, const float* a1, int lda1,
+             const float* b0, int ldb0, const float* b1, int ldb1,
+             float* c, int ldc, const float* bias, const float* res, int ldres,
+             const float* gate, int ldgate, float gate_scale, float* bias_grad,
+             int relu_a, int relu_b, int relu_out, int accumulate,
+             uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile, m2f_stream_t stream);
+/* softmax(q k^T / sqrt(hd) + key_padding_mask) v per (dialogue, head) (nn.MultiheadAttention inside
+ * src/model.py:8,14,61,73); probs receives P^T per head, padded to Lp = 16*ceil(L/16). */
+int m2f_attention_fwd(int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk,
+                      const float* v, int ldv, const uint8_t* key_pad, float* out, int ldo, float* probs,
+                      uint32_t drop_site, float drop_p, const uint32_t* rng_state, m2f_stream_t stream);
+int m2f_attention_bwd(int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk,
+                      const float* v, int ldv, const uint8_t* key_pad, const float* out, int ldo,
+                      const float* probs, const float* dout, int lddo, float* dq, int lddq, float* dk,
+                      int lddk, float* dv, int lddv, uint32_t drop_site, float drop_p,
+                      const uint32_t* rng_state, m2f_stream_t stream);
+int64_t m2f_attention_probs_elems(int B, int H, int L);
+/* out = (res ? res : 0) + LayerNorm(x) (nn.LayerNorm, eps), stats[T,2] = (mean, rstd). */
+int m2f_layernorm_fwd(int T, int d, const float* x, const float* gamma, const float* beta, const float* res,
+                      float* out, float* stats, float eps, m2f_stream_t stream);
+/* dx = LayerNorm backward (+extra); dgamma/dbeta via per-block partials (partial: [ceil(T/16), 2, d]). */
+int m2f_layernorm_bwd(int T, int d, const float* x, const float* gamma, const float* stats, const float* dy,
+                      const float* extra, float* dx, float* partial, float* dgamma, float* dbeta,
+                      m2f_stream_t stream);
+/* CrossEntropyLoss(ignore_index=-1, label_smoothing[, weight]) + gradient; loss_out[0..2] = loss, den, num. */
+int m2f_cross_entropy(int T, int C, const float* logits, const int64_t* labels, const float* class_w,
+                      float label_smoothing, int normalise, float* loss_terms, float* dlogits, float* loss_out,
+                      m2f_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2FNET_HIP_H */

@@ -1,0 +1,46 @@
+// Shared device helpers for the M2FNet gfx950 kernels (wave64, MFMA, LDS).
+// gfx950 only: no CUDA shims, no alternate back-ends.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define M2F_WAVE 64
+
+// ---- counter-based dropout RNG -----------------------------------------------------------------
+// The state lives in device memory (4 x u32: seed_lo, seed_hi, step_lo, step_hi) so a captured
+// hipGraph replays with a fresh stream of masks each step (a 1-thread kernel bumps `step`).
+// keep(site, idx) is a pure function of (state, site, idx): the backward pass regenerates the
+// forward mask instead of storing it.
+__device__ __forceinline__ uint32_t m2f_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t m2f_site_key(const uint32_t* __restrict__ rng, uint32_t site) {
+    uint32_t k = m2f_mix32(rng[0] ^ 0x9e3779b9U);
+    k = m2f_mix32(k ^ rng[1]);
+    k = m2f_mix32(k + rng[2] * 0x85ebca6bU);
+    k = m2f_mix32(k ^ (rng[3] + site * 0xc2b2ae35U));
+    return k;
+}
+__device__ __forceinline__ bool m2f_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
+    uint32_t h = m2f_mix32(idx * 0x9E3779B1U + key);
+    h = m2f_mix32(h ^ (key >> 7) ^ 0x68e31da4U);
+    return h >= thresh;       // P(keep) = 1 - thresh / 2^32
+}
+
+__device__ __forceinline__ float m2f_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float m2f_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int m2f_cdiv(int a, int b) { return (a + b - 1) / b; }

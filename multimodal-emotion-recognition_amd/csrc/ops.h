@@ -1,0 +1,151 @@
+// Internal launch interfaces of the gfx950 kernels (host side). The public C ABI is include/m2fnet_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ------------------------------------------------------------------------------------------------
+// Grouped GEMM:  C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+//   operand layouts   KC: element (row, k) at p[row*ld + k]   (k contiguous)
+//                     RC: element (row, k) at p[k*ld + row]   (row contiguous)
+//   forward  Y  = X W^T        A = X  KC, B = W  KC
+//   dgrad    dX = dY W         A = dY KC, B = W  RC   (reduction over W's row index)
+//   wgrad    dW = dY^T X       A = dY RC, B = X  RC   (reduction over tokens)
+//   Each operand may be the concatenation of two segments along k (cat(x, text) of the FAM layer,
+//   src/model.py:16, is never materialised).
+//   epilogue order: +bias[n] -> relu -> dropout(site) -> +res[m,n] -> *(gate[m,n] > 0 ? gate_scale : 0)
+//                   -> (C += | C =)
+// ------------------------------------------------------------------------------------------------
+enum { M2F_PREC_F32 = 0, M2F_PREC_BF16 = 1 };
+enum { M2F_LAYOUT_NT = 0, M2F_LAYOUT_NN = 1, M2F_LAYOUT_TN = 2 };   // fwd / dgrad / wgrad
+enum {
+    GF_RELU_A = 1, GF_RELU_B = 2, GF_RELU_OUT = 4, GF_ACCUM = 8,
+    GF_VEC_A = 16, GF_VEC_B = 32     // set by the launcher when 16-byte loads are legal
+};
+
+struct GemmOperand {
+    const float* p[2];
+    int ld[2];
+    int k[2];          // reduction length of each segment (k[1] == 0: single segment)
+};
+
+struct GemmProblem {
+    GemmOperand a, b;
+    float* c;
+    const float* bias;        // [N] or null
+    const float* res;         // [M, N] (ldres) or null
+    const float* gate;        // [M, N] (ldgate) or null
+    float* bias_grad;         // wgrad only: [M] column sums of A over the reduction dim, or null
+    int M, N, ldc, ldres, ldgate;
+    float gate_scale;
+    uint32_t drop_site;       // 0 = no dropout in the epilogue
+    uint32_t flags;
+    int tile_begin, tiles_n;  // filled by the launcher
+};
+
+#define M2F_GEMM_MAX_PROBLEMS 8
+struct GemmBatch {
+    GemmProblem pr[M2F_GEMM_MAX_PROBLEMS];
+    int count;
+    const uint32_t* rng;      // dropout RNG state (device), may be null when no problem has drop_site
+    uint32_t drop_thresh;     // p * 2^32
+    float drop_scale;         // 1 / (1 - p)
+};
+
+// Launches one grouped GEMM. Returns hipSuccess or the launch error. `tile` = 0 (auto), 64 or 128.
+hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// Attention (one wavefront per (dialogue, head); Q/K/V tiles staged in LDS, fp32 MFMA 16x16x4,
+// wavefront-shuffle softmax).  Rows of q/k/v/out are token-major: token t = b*L + i.
+// ------------------------------------------------------------------------------------------------
+struct AttnProblem {
+    const float* q; const float* k; const float* v;   // head h occupies columns [h*hd, (h+1)*hd)
+    int ldq, ldk, ldv;
+    float* out; int ldo;                               // [T, H*hd]
+    float* probs;                                      // [B*H, Lp, Lp] saved P^T (pre-dropout), Lp = 16*ceil(L/16)
+    // backward only
+    const float* dout; int lddo;
+    float* dq; float* dk; float* dv; int lddq, lddk, lddv;
+    int H, hd;
+    uint32_t drop_site;
+    int block_begin;                                   // filled by the launcher
+};
+#define M2F_ATTN_MAX_PROBLEMS 4
+struct AttnBatch {
+    AttnProblem pr[M2F_ATTN_MAX_PROBLEMS];
+    int count;
+    int B, L;
+    const uint8_t* key_pad;    // [B, L], 1 = padded key
+    const uint32_t* rng;
+    uint32_t drop_thresh;
+    float drop_scale;
+};
+hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
+hipError_t m2f_launch_attn_bwd(AttnBatch& ab, hipStream_t stream);
+size_t m2f_attn_probs_elems(int B, int H, int L);
+
+// ------------------------------------------------------------------------------------------------
+// Row-wise kernels
+// ------------------------------------------------------------------------------------------------
+struct LnProblem {
+    // forward: y = LN(x)*gamma + beta ; out = (res ? res : 0) + y ; optional dropout(out)
+    const float* x; const float* gamma; const float* beta; const float* res;
+    float* out; float* stats;          // stats [T, 2] = (mean, rstd)
+    int d;
+    uint32_t drop_site;
+    // backward: dx = LNbwd(dy) (+ extra) ; optional second output dx_masked = LNbwd(dy) * keep(site2)/(1-p)
+    const float* dy; const float* extra;
+    float* dx; float* dx_masked;
+    float* partial;                    // [n_row_blocks, 2, d] partial (dgamma, dbeta)
+    uint32_t drop_site2;
+    int block_begin;
+};
+#define M2F_LN_MAX_PROBLEMS 4
+struct LnBatch {
+    LnProblem pr[M2F_LN_MAX_PROBLEMS];
+    int count;
+    int T;
+    float eps;
+    const uint32_t* rng; uint32_t drop_thresh; float drop_scale;
+};
+#define M2F_LN_ROWS_PER_BLOCK 16
+hipError_t m2f_launch_ln_fwd(LnBatch& lb, hipStream_t stream);
+hipError_t m2f_launch_ln_bwd(LnBatch& lb, hipStream_t stream);
+static inline int m2f_ln_row_blocks(int T) { return (T + M2F_LN_ROWS_PER_BLOCK - 1) / M2F_LN_ROWS_PER_BLOCK; }
+
+// dgamma/dbeta = sum over row blocks of the partials, for many LayerNorms in one launch.
+struct LnReduceItem { const float* partial; float* dgamma; float* dbeta; int d; int nblk; };
+#define M2F_LNRED_MAX_ITEMS 32
+struct LnReduceBatch { LnReduceItem it[M2F_LNRED_MAX_ITEMS]; int count; };
+hipError_t m2f_launch_ln_param_reduce(const LnReduceBatch& rb, hipStream_t stream);
+
+// Criterion of src/train.py:48-50 on logits [T, C] (C <= 16): CrossEntropyLoss(ignore_index=-1,
+// label_smoothing, optional class weights).  Per token it writes the loss numerator / denominator
+// terms and the UNNORMALISED gradient d(sum of numerators)/dlogits.
+struct CeArgs {
+    const float* logits; int T, C;
+    const int64_t* labels;                 // [T], ignore_index = -1
+    const float* class_w;                  // [C] or null
+    float label_smoothing;
+    float* loss_terms;                     // [T, 2] (numerator, denominator)
+    float* dlogits;                        // [T, C]
+};
+hipError_t m2f_launch_ce(const CeArgs& a, hipStream_t stream);
+// loss_out[0] = num/den, loss_out[1] = den, loss_out[2] = num.  normalise != 0: dlogits *= 1/den
+// (single-process mean-over-valid loss); normalise == 0 leaves the sum-gradient for the data-parallel
+// path, which divides by the GLOBAL denominator after the all-reduce.
+hipError_t m2f_launch_loss_finalize(const float* loss_terms, int T, int C, float* dlogits, float* loss_out,
+                                    int normalise, hipStream_t stream);
+
+// in-place: x[t, c] *= keep(site, t*d + c) / (1 - p)
+hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
+                                      uint32_t thresh, float scale, hipStream_t stream);
+// rng.step += 1 (device side, graph-replay safe)
+hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream);
+
+// Fused Adam with coupled L2 (torch.optim.Adam semantics, src/train.py:56) over the flat buffers.
+// grad_scale_ptr (device, may be null): gradients are multiplied by 1 / *grad_scale_ptr first (the
+// global valid-utterance denominator under data parallelism).
+hipError_t m2f_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
+                           hipStream_t stream);

@@ -1,0 +1,1052 @@
+// Plan builder / executor and the C ABI (include/m2fnet_hip.h) of the M2FNet training step on gfx950.
+//
+// A plan is the complete launch list of one step (forward, criterion, backward) for fixed
+// (config, B, L, precision, train/eval), bound to caller-owned device buffers.  Built once, then replayed
+// either eagerly or as one hipGraph.  MI355X-first decisions encoded here:
+//   * the two modality branches (audio / text encoders) are independent until the fusion stack, so their
+//     launch chains are MERGED pairwise into grouped launches (longest-common-subsequence alignment):
+//     half the launches, twice the workgroups per launch on a chip with 256 CUs;
+//   * every weight-gradient GEMM is DEFERRED: with 288 GB of HBM all dY / X operands stay resident, so the
+//     ~100 wgrad problems run as a handful of chip-filling grouped launches after the latency-bound
+//     input-gradient chain instead of being interleaved with it;
+//   * torch.cat is never materialised (two-segment GEMM operands), bias/ReLU/dropout/residual/ReLU-gate
+//     live in GEMM epilogues, dropout masks are regenerated from a counter RNG in backward.
+// Math follows the reference: src/model.py:102-145 (M2FNet.forward), :13-20 (FusionAttentionModule),
+// torch TransformerEncoderLayer (post-LN, ReLU, eps 1e-5, dim_feedforward 2048), src/train.py:48-50 (CE).
+#include "../../include/m2fnet_hip.h"
+#include "common.h"
+#include "ops.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return 1; }
+int hipfail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return 2;
+}
+#define M2F_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hipfail(e_, #x); } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// parameter map (mirror of layout.py / reference state_dict order)
+// ---------------------------------------------------------------------------------------------------
+struct EncLayerP { size_t in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b; };
+struct ModalityP { std::vector<std::vector<EncLayerP>> enc; size_t norm_w = 0, norm_b = 0, proj_w = 0, proj_b = 0; };
+struct FamP { size_t in_w, in_b, out_w, out_b, lin_w, lin_b; };
+struct LinP { size_t w, b; };
+struct ParamMap {
+    ModalityP audio, text;
+    std::vector<FamP> fam;
+    std::vector<LinP> cls;               // Linear0, extra hidden..., last
+    std::vector<int64_t> offsets, numels;
+    size_t total = 0;
+};
+
+size_t pm_add(ParamMap& pm, size_t n) {
+    const size_t off = pm.total;
+    pm.offsets.push_back((int64_t)off);
+    pm.numels.push_back((int64_t)n);
+    pm.total = (off + n + 63) / 64 * 64;
+    return off;
+}
+
+void pm_modality(ParamMap& pm, ModalityP& m, int d, int ntrans, int nlayers, int dff, int dfam) {
+    m.enc.resize(ntrans);
+    for (int e = 0; e < ntrans; ++e) {
+        for (int l = 0; l < nlayers; ++l) {
+            EncLayerP p;
+            p.in_w = pm_add(pm, (size_t)3 * d * d);
+            p.in_b = pm_add(pm, (size_t)3 * d);
+            p.out_w = pm_add(pm, (size_t)d * d);
+            p.out_b = pm_add(pm, d);
+            p.l1_w = pm_add(pm, (size_t)dff * d);
+            p.l1_b = pm_add(pm, dff);
+            p.l2_w = pm_add(pm, (size_t)d * dff);
+            p.l2_b = pm_add(pm, d);
+            p.n1_w = pm_add(pm, d);
+            p.n1_b = pm_add(pm, d);
+            p.n2_w = pm_add(pm, d);
+            p.n2_b = pm_add(pm, d);
+            m.enc[e].push_back(p);
+        }
+        if (e == 0) {                       // the final norm object is shared by all encoders of a modality
+            m.norm_w = pm_add(pm, d);
+            m.norm_b = pm_add(pm, d);
+        }
+    }
+    m.proj_w = pm_add(pm, (size_t)dfam * d);
+    m.proj_b = pm_add(pm, dfam);
+}
+
+int cls_in_width(const m2f_config& c) { return (c.audio_enabled && c.text_enabled) ? 2 * c.d_fam : c.d_fam; }
+
+int check_config(const m2f_config& c) {
+    if (!c.audio_enabled && !c.text_enabled) return fail("At least one of audio and text must be enabled!");
+    if (c.fam_enabled && !(c.audio_enabled && c.text_enabled))
+        return fail("Fusion Attention Module can only be used with both audio and text enabled!");
+    if (c.audio_enabled && (c.nhead_audio < 1 || c.d_audio % c.nhead_audio)) return fail("AUDIO: embed_dim must be divisible by num_heads");
+    if (c.text_enabled && (c.nhead_text < 1 || c.d_text % c.nhead_text)) return fail("TEXT: embed_dim must be divisible by num_heads");
+    if (c.fam_enabled && (c.nhead_fam < 1 || c.d_fam % c.nhead_fam)) return fail("FAM: embed_dim must be divisible by num_heads");
+    if (c.cls_out < 1 || c.cls_out > 16) return fail("CLASSIFIER.output_size must be in [1,16]");
+    if (c.dropout < 0.f || c.dropout >= 1.f) return fail("dropout must be in [0,1)");
+    if (c.dim_ff < 1 || c.cls_hidden < 1 || c.d_fam < 1) return fail("bad widths");
+    const int dmax = std::max(std::max(c.audio_enabled ? c.d_audio : 0, c.text_enabled ? c.d_text : 0), c.d_fam);
+    if (dmax > 2048) return fail("embedding sizes above 2048 are not supported by the LayerNorm kernels");
+    return 0;
+}
+
+int build_param_map(const m2f_config& c, ParamMap& pm) {
+    if (check_config(c)) return 1;
+    if (c.audio_enabled) pm_modality(pm, pm.audio, c.d_audio, c.ntrans_audio, c.nlayers_audio, c.dim_ff, c.d_fam);
+    if (c.text_enabled) pm_modality(pm, pm.text, c.d_text, c.ntrans_text, c.nlayers_text, c.dim_ff, c.d_fam);
+    if (c.fam_enabled) {
+        const size_t E = c.d_fam;
+        for (int i = 0; i < c.nlayers_fam; ++i) {
+            FamP f;
+            f.in_w = pm_add(pm, 3 * E * E);
+            f.in_b = pm_add(pm, 3 * E);
+            f.out_w = pm_add(pm, E * E);
+            f.out_b = pm_add(pm, E);
+            f.lin_w = pm_add(pm, E * 2 * E);
+            f.lin_b = pm_add(pm, E);
+            pm.fam.push_back(f);
+        }
+    }
+    const size_t h = c.cls_hidden, in = cls_in_width(c);
+    LinP l0;
+    l0.w = pm_add(pm, h * in);
+    l0.b = pm_add(pm, h);
+    pm.cls.push_back(l0);
+    for (int j = 0; j < std::max(c.cls_layers - 2, 0); ++j) {
+        LinP l;
+        l.w = pm_add(pm, h * h);
+        l.b = pm_add(pm, h);
+        pm.cls.push_back(l);
+    }
+    LinP ll;
+    ll.w = pm_add(pm, (size_t)c.cls_out * h);
+    ll.b = pm_add(pm, c.cls_out);
+    pm.cls.push_back(ll);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ops, launches
+// ---------------------------------------------------------------------------------------------------
+enum OpKind { OP_GEMM, OP_ATTN_FWD, OP_ATTN_BWD, OP_LN_FWD, OP_LN_BWD, OP_DROPOUT };
+
+struct Op {
+    int kind = OP_GEMM;
+    int layout = M2F_LAYOUT_NT;
+    std::vector<GemmProblem> gp;
+    std::vector<AttnProblem> ap;
+    std::vector<LnProblem> lp;
+    float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;      // OP_DROPOUT
+};
+
+struct Launch {
+    int kind = OP_GEMM;
+    int layout = M2F_LAYOUT_NT;
+    GemmBatch gb;
+    AttnBatch ab;
+    LnBatch lb;
+    float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    template <typename T> T* alloc(size_t n) {
+        off = (off + 255) / 256 * 256;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+    float* f(size_t n) { return alloc<float>(n); }
+};
+
+GemmProblem gp_make(const float* a, int lda, const float* b, int ldb, int M, int N, int K, float* c, int ldc) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.a.p[0] = a; p.a.ld[0] = lda; p.a.k[0] = K;
+    p.b.p[0] = b; p.b.ld[0] = ldb; p.b.k[0] = K;
+    p.M = M; p.N = N; p.c = c; p.ldc = ldc; p.gate_scale = 1.f;
+    return p;
+}
+void gp_seg2(GemmProblem& p, const float* a1, int lda1, const float* b1, int ldb1, int K1) {
+    p.a.p[1] = a1; p.a.ld[1] = lda1; p.a.k[1] = K1;
+    p.b.p[1] = b1; p.b.ld[1] = ldb1; p.b.k[1] = K1;
+}
+Op op_gemm(int layout, const GemmProblem& p) { Op o; o.kind = OP_GEMM; o.layout = layout; o.gp.push_back(p); return o; }
+
+struct EncLayerBuf {
+    const float* y_in; float *qkv, *probs, *att, *s1, *st1, *y1, *h, *s2, *st2, *y2;
+    uint32_t site_attn, site_d1, site_ff, site_d2;
+};
+struct ModBuf {
+    int d = 0, H = 0, nl = 0, nt = 0;
+    const float* x_in = nullptr;
+    std::vector<std::vector<EncLayerBuf>> L;
+    std::vector<float*> xe, stf;
+    float* xp = nullptr;
+    uint32_t site_pre = 0, site_post = 0;
+};
+struct FamBuf { const float* t_in; float *qv, *k, *probs, *att, *x, *t_out; uint32_t site_attn, site_out; };
+
+}  // namespace
+
+struct m2f_plan {
+    m2f_config cfg;
+    int B = 0, L = 0, T = 0, prec = 0, train = 0;
+    float* params = nullptr;
+    float* grads = nullptr;
+    uint32_t* rng = nullptr;
+    uint32_t drop_thresh = 0;
+    float drop_scale = 1.f;
+    bool use_dropout = false;
+    ParamMap pm;
+    void* bufs[M2F_BUF_COUNT] = {nullptr};
+    float* loss_terms = nullptr;
+    std::vector<Launch> fwd, bwd;
+    std::vector<LnReduceBatch> lnred;
+    size_t ws_used = 0;
+    // graph cache for m2f_step
+    hipGraphExec_t gexec = nullptr;
+    float g_ls = 0.f; int g_cw = -1, g_norm = -1;
+    bool warmed = false;          // one eager step (sets kernel attributes) before the first capture
+    ~m2f_plan() { if (gexec) (void)hipGraphExecDestroy(gexec); }
+};
+
+namespace {
+
+struct Builder {
+    m2f_plan& P;
+    Arena ar;
+    uint32_t next_site = 1;
+    std::vector<Op> chain_f;                   // sequential forward ops after the branches (FAM, classifier)
+    std::vector<Op> br_f[2], br_b[2];          // per-branch (0 audio, 1 text) forward / backward chains
+    std::vector<Op> chain_b;                   // classifier + FAM backward (before the branches)
+    std::vector<GemmProblem> wgrads;           // deferred weight-gradient problems (TN)
+    std::vector<LnReduceItem> lnitems;
+    ModBuf mod[2];
+    std::vector<FamBuf> fam;
+    int T;
+
+    explicit Builder(m2f_plan& p) : P(p), T(p.T) {}
+
+    uint32_t site() { return P.use_dropout ? next_site++ : 0u; }
+    const float* W(size_t off) const { return P.params + off; }
+    float* G(size_t off) const { return P.grads ? P.grads + off : nullptr; }
+    float gscale() const { return P.use_dropout ? P.drop_scale : 1.f; }
+
+    Op op_ln_fwd(const float* x, size_t gw, size_t gb, const float* res, float* out, float* stats, int d, uint32_t s) {
+        Op o; o.kind = OP_LN_FWD;
+        LnProblem p; memset(&p, 0, sizeof(p));
+        p.x = x; p.gamma = W(gw); p.beta = W(gb); p.res = res; p.out = out; p.stats = stats; p.d = d; p.drop_site = s;
+        o.lp.push_back(p);
+        return o;
+    }
+    // shared_partial != null: the LayerNorm object is shared (final encoder norm): the caller owns one partial
+    // buffer for all its uses and registers a single reduce item covering every slice.
+    Op op_ln_bwd(const float* x, size_t gw, size_t gb, const float* stats, const float* dy, const float* extra,
+                 float* dx, float* dx_masked, int d, uint32_t s2, float* shared_partial = nullptr) {
+        Op o; o.kind = OP_LN_BWD;
+        LnProblem p; memset(&p, 0, sizeof(p));
+        p.x = x; p.gamma = W(gw); p.stats = const_cast<float*>(stats); p.dy = dy; p.extra = extra; p.dx = dx;
+        p.dx_masked = dx_masked; p.d = d; p.drop_site2 = s2;
+        const int nblk = m2f_ln_row_blocks(T);
+        p.partial = shared_partial ? shared_partial : ar.f((size_t)nblk * 2 * d);
+        o.lp.push_back(p);
+        if (!shared_partial) {
+            LnReduceItem it; it.partial = p.partial; it.dgamma = G(gw); it.dbeta = G(gb); it.d = d; it.nblk = nblk;
+            lnitems.push_back(it);
+        }
+        return o;
+    }
+    void wgrad(const float* dy, int lddy, const float* x, int ldx, int Nw, int Kw, size_t w_off, int ldw, long b_off,
+               bool relu_b = false) {
+        // dW[Nw, Kw] = dY[T, Nw]^T X[T, Kw]; bias grad = column sums of dY
+        GemmProblem p = gp_make(dy, lddy, x, ldx, Nw, Kw, T, G(w_off), ldw);
+        if (b_off >= 0) p.bias_grad = G((size_t)b_off);
+        if (relu_b) p.flags |= GF_RELU_B;
+        wgrads.push_back(p);
+    }
+
+    // ---------------- modality branch: encoders + projection --------------------------------------
+    void build_modality(int bi, const ModalityP& mp, int d, int H, int nl, int nt, const float* x_in) {
+        ModBuf& m = mod[bi];
+        m.d = d; m.H = H; m.nl = nl; m.nt = nt; m.x_in = x_in;
+        const int F = P.cfg.dim_ff, E = P.cfg.d_fam;
+        std::vector<Op>& f = br_f[bi];
+        const float* x = x_in;
+        m.L.resize(nt);
+        for (int e = 0; e < nt; ++e) {
+            const float* y = x;
+            for (int l = 0; l < nl; ++l) {
+                const EncLayerP& p = mp.enc[e][l];
+                EncLayerBuf b;
+                b.y_in = y;
+                b.qkv = ar.f((size_t)T * 3 * d);
+                b.probs = ar.f(m2f_attn_probs_elems(P.B, H, P.L));
+                b.att = ar.f((size_t)T * d);
+                b.s1 = ar.f((size_t)T * d);
+                b.st1 = ar.f((size_t)T * 2);
+                b.y1 = ar.f((size_t)T * d);
+                b.h = ar.f((size_t)T * F);
+                b.s2 = ar.f((size_t)T * d);
+                b.st2 = ar.f((size_t)T * 2);
+                b.y2 = ar.f((size_t)T * d);
+                b.site_attn = site(); b.site_d1 = site(); b.site_ff = site(); b.site_d2 = site();
+                {   // packed QKV in-projection
+                    GemmProblem g = gp_make(y, d, W(p.in_w), d, T, 3 * d, d, b.qkv, 3 * d);
+                    g.bias = W(p.in_b);
+                    f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+                }
+                {
+                    Op o; o.kind = OP_ATTN_FWD;
+                    AttnProblem a; memset(&a, 0, sizeof(a));
+                    a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+                    a.out = b.att; a.ldo = d; a.probs = b.probs; a.H = H; a.hd = d / H; a.drop_site = b.site_attn;
+                    o.ap.push_back(a);
+                    f.push_back(o);
+                }
+                {   // out-proj -> dropout1 -> + residual
+                    GemmProblem g = gp_make(b.att, d, W(p.out_w), d, T, d, d, b.s1, d);
+                    g.bias = W(p.out_b); g.drop_site = b.site_d1; g.res = y; g.ldres = d;
+                    f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+                }
+                f.push_back(op_ln_fwd(b.s1, p.n1_w, p.n1_b, nullptr, b.y1, b.st1, d, 0));
+                {   // linear1 -> relu -> dropout
+                    GemmProblem g = gp_make(b.y1, d, W(p.l1_w), d, T, F, d, b.h, F);
+                    g.bias = W(p.l1_b); g.flags |= GF_RELU_OUT; g.drop_site = b.site_ff;
+                    f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+                }
+                {   // linear2 -> dropout2 -> + residual
+                    GemmProblem g = gp_make(b.h, F, W(p.l2_w), F, T, d, F, b.s2, d);
+                    g.bias = W(p.l2_b); g.drop_site = b.site_d2; g.res = b.y1; g.ldres = d;
+                    f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+                }
+                f.push_back(op_ln_fwd(b.s2, p.n2_w, p.n2_b, nullptr, b.y2, b.st2, d, 0));
+                y = b.y2;
+                m.L[e].push_back(b);
+            }
+            // x_e = x_{e-1} + LNf(y); the last one feeds `dropout -> proj` (src/model.py:111,123)
+            float* xe = ar.f((size_t)T * d);
+            float* stf = ar.f((size_t)T * 2);
+            const uint32_t s = (e == nt - 1) ? (m.site_pre = site()) : 0u;
+            f.push_back(op_ln_fwd(y, mp.norm_w, mp.norm_b, x, xe, stf, d, s));
+            m.xe.push_back(xe);
+            m.stf.push_back(stf);
+            x = xe;
+        }
+        m.xp = ar.f((size_t)T * E);
+        m.site_post = site();
+        {
+            GemmProblem g = gp_make(x, d, W(mp.proj_w), d, T, E, d, m.xp, E);
+            g.bias = W(mp.proj_b); g.drop_site = m.site_post;
+            f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+        }
+    }
+
+    // backward of a modality branch given d(xp) (already masked by the post-proj dropout)
+    void build_modality_bwd(int bi, const ModalityP& mp, const float* dxp) {
+        ModBuf& m = mod[bi];
+        const int d = m.d, H = m.H, nl = m.nl, nt = m.nt, F = P.cfg.dim_ff, E = P.cfg.d_fam;
+        std::vector<Op>& bw = br_b[bi];
+        const float* x_last = nt > 0 ? m.xe[nt - 1] : m.x_in;
+        wgrad(dxp, E, x_last, d, E, d, mp.proj_w, d, (long)mp.proj_b);
+        if (nt == 0) return;
+        float* dx = ar.f((size_t)T * d);
+        {
+            GemmProblem g = gp_make(dxp, E, W(mp.proj_w), d, T, d, E, dx, d);
+            g.drop_site = m.site_pre;
+            bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
+        }
+        const float* dxe = dx;
+        const int nblk = m2f_ln_row_blocks(T);
+        float* normp = ar.f((size_t)nt * nblk * 2 * d);       // one slice per use of the shared final norm
+        {
+            LnReduceItem it; it.partial = normp; it.dgamma = G(mp.norm_w); it.dbeta = G(mp.norm_b); it.d = d; it.nblk = nt * nblk;
+            lnitems.push_back(it);
+        }
+        for (int e = nt - 1; e >= 0; --e) {
+            const float* yN = nl > 0 ? m.L[e][nl - 1].y2 : (e > 0 ? m.xe[e - 1] : m.x_in);
+            float* g_cur = ar.f((size_t)T * d);
+            bw.push_back(op_ln_bwd(yN, mp.norm_w, mp.norm_b, m.stf[e], dxe, nullptr, g_cur, nullptr, d, 0,
+                                   normp + (size_t)e * nblk * 2 * d));
+            const float* gy = g_cur;
+            const bool need_in = e > 0;          // gradient w.r.t. this encoder's input is needed
+            for (int l = nl - 1; l >= 0; --l) {
+                const EncLayerP& p = mp.enc[e][l];
+                const EncLayerBuf& b = m.L[e][l];
+                const bool first = (l == 0);
+                // LN2
+                float* ds2 = ar.f((size_t)T * d);
+                float* ds2m = b.site_d2 ? ar.f((size_t)T * d) : nullptr;
+                bw.push_back(op_ln_bwd(b.s2, p.n2_w, p.n2_b, b.st2, gy, nullptr, ds2, ds2m, d, b.site_d2));
+                const float* ds2g = ds2m ? ds2m : ds2;
+                wgrad(ds2g, d, b.h, F, d, F, p.l2_w, F, (long)p.l2_b);
+                float* dh = ar.f((size_t)T * F);
+                {
+                    GemmProblem g = gp_make(ds2g, d, W(p.l2_w), F, T, F, d, dh, F);
+                    g.gate = b.h; g.ldgate = F; g.gate_scale = b.site_ff ? P.drop_scale : 1.f;
+                    bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
+                }
+                wgrad(dh, F, b.y1, d, F, d, p.l1_w, d, (long)p.l1_b);
+                float* dy1 = ar.f((size_t)T * d);
+                {
+                    GemmProblem g = gp_make(dh, F, W(p.l1_w), d, T, d, F, dy1, d);
+                    g.res = ds2; g.ldres = d;
+                    bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
+                }
+                // LN1 (+ the encoder-level residual d x_{e-1} += d x_e on the first layer)
+                const float* extra = (first && need_in) ? dxe : nullptr;
+                float* ds1 = ar.f((size_t)T * d);
+                float* ds1m = (b.site_d1 || extra) ? ar.f((size_t)T * d) : nullptr;
+                bw.push_back(op_ln_bwd(b.s1, p.n1_w, p.n1_b, b.st1, dy1, extra, ds1, ds1m, d, b.site_d1));
+                const float* ds1g = ds1m ? ds1m : ds1;
+                wgrad(ds1g, d, b.att, d, d, d, p.out_w, d, (long)p.out_b);
+                float* datt = ar.f((size_t)T * d);
+                bw.push_back(op_gemm(M2F_LAYOUT_NN, gp_make(ds1g, d, W(p.out_w), d, T, d, d, datt, d)));
+                float* dqkv = ar.f((size_t)T * 3 * d);
+                {
+                    Op o; o.kind = OP_ATTN_BWD;
+                    AttnProblem a; memset(&a, 0, sizeof(a));
+                    a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+                    a.out = b.att; a.ldo = d; a.probs = b.probs; a.H = H; a.hd = d / H; a.drop_site = b.site_attn;
+                    a.dout = datt; a.lddo = d;
+                    a.dq = dqkv; a.dk = dqkv + d; a.dv = dqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
+                    o.ap.push_back(a);
+                    bw.push_back(o);
+                }
+                wgrad(dqkv, 3 * d, b.y_in, d, 3 * d, d, p.in_w, d, (long)p.in_b);
+                if (!first || need_in) {
+                    float* gn = ar.f((size_t)T * d);
+                    GemmProblem g = gp_make(dqkv, 3 * d, W(p.in_w), d, T, d, 3 * d, gn, d);
+                    g.res = ds1; g.ldres = d;            // ds1 already carries the encoder-level residual
+                    bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
+                    gy = gn;
+                }
+            }
+            dxe = gy;
+        }
+    }
+
+    // ---------------- fusion stack + classifier ------------------------------------------------------
+    void build_head() {
+        const m2f_config& c = P.cfg;
+        const int E = c.d_fam, Hf = c.nhead_fam;
+        const bool a_on = c.audio_enabled, t_on = c.text_enabled;
+        const float* a = a_on ? mod[0].xp : nullptr;
+        const float* t = t_on ? mod[1].xp : nullptr;
+        if (c.fam_enabled) {
+            // all K projections read the same (layer-invariant) audio tensor: one grouped launch per 8 layers
+            std::vector<float*> kbuf;
+            for (int i = 0; i < c.nlayers_fam; ++i) kbuf.push_back(ar.f((size_t)T * E));
+            for (int i0 = 0; i0 < c.nlayers_fam; i0 += M2F_GEMM_MAX_PROBLEMS) {
+                Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NT;
+                for (int i = i0; i < std::min(c.nlayers_fam, i0 + M2F_GEMM_MAX_PROBLEMS); ++i) {
+                    const FamP& p = P.pm.fam[i];
+                    GemmProblem g = gp_make(a, E, W(p.in_w + (size_t)E * E), E, T, E, E, kbuf[i], E);
+                    g.bias = W(p.in_b + E);
+                    o.gp.push_back(g);
+                }
+                chain_f.push_back(o);
+            }
+            for (int i = 0; i < c.nlayers_fam; ++i) {
+                const FamP& p = P.pm.fam[i];
+                FamBuf b;
+                b.t_in = t;
+                b.qv = ar.f((size_t)T * 2 * E);
+                b.k = kbuf[i];
+                b.probs = ar.f(m2f_attn_probs_elems(P.B, Hf, P.L));
+                b.att = ar.f((size_t)T * E);
+                b.x = ar.f((size_t)T * E);
+                b.t_out = ar.f((size_t)T * E);
+                b.site_attn = site(); b.site_out = site();
+                {   // q = t Wq^T + bq -> qv[:, :E] ; v = t Wv^T + bv -> qv[:, E:]
+                    Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NT;
+                    GemmProblem gq = gp_make(t, E, W(p.in_w), E, T, E, E, b.qv, 2 * E);
+                    gq.bias = W(p.in_b);
+                    GemmProblem gv = gp_make(t, E, W(p.in_w + (size_t)2 * E * E), E, T, E, E, b.qv + E, 2 * E);
+                    gv.bias = W(p.in_b + 2 * E);
+                    o.gp.push_back(gq); o.gp.push_back(gv);
+                    chain_f.push_back(o);
+                }
+                {
+                    Op o; o.kind = OP_ATTN_FWD;
+                    AttnProblem at; memset(&at, 0, sizeof(at));
+                    at.q = b.qv; at.ldq = 2 * E; at.k = b.k; at.ldk = E; at.v = b.qv + E; at.ldv = 2 * E;
+                    at.out = b.att; at.ldo = E; at.probs = b.probs; at.H = Hf; at.hd = E / Hf; at.drop_site = b.site_attn;
+                    o.ap.push_back(at);
+                    chain_f.push_back(o);
+                }
+                {
+                    GemmProblem g = gp_make(b.att, E, W(p.out_w), E, T, E, E, b.x, E);
+                    g.bias = W(p.out_b);
+                    chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+                }
+                {   // relu(Linear(relu(cat(x, t)))) -> dropout   (src/model.py:16-19,131)
+                    GemmProblem g = gp_make(b.x, E, W(p.lin_w), 2 * E, T, E, E, b.t_out, E);
+                    gp_seg2(g, t, E, W(p.lin_w) + E, 2 * E, E);
+                    g.bias = W(p.lin_b); g.flags |= GF_RELU_A | GF_RELU_OUT; g.drop_site = b.site_out;
+                    chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+                }
+                t = b.t_out;
+                fam.push_back(b);
+            }
+            P.bufs[M2F_BUF_FAM0_OUT] = fam.empty() ? nullptr : fam[0].t_out;
+        }
+        // classifier (src/model.py:89-100,143): Linear0, [ReLU, Linear]*(n-2), ReLU, Dropout, Linear
+        const int hid = c.cls_hidden, C = c.cls_out;
+        const int nhid = (int)P.pm.cls.size() - 1;           // hidden activations h[0..nhid-1]
+        std::vector<float*> hbuf;
+        std::vector<uint32_t> hsite;
+        const float* s0 = (a_on && t_on) ? a : (t_on ? t : a);
+        const float* s1 = (a_on && t_on) ? t : nullptr;
+        for (int j = 0; j < nhid; ++j) {
+            float* h = ar.f((size_t)T * hid);
+            const uint32_t s = (j == nhid - 1) ? site() : 0u;
+            const LinP& lp = P.pm.cls[j];
+            GemmProblem g;
+            if (j == 0) {
+                const int ldw = cls_in_width(c);
+                g = gp_make(s0, E, W(lp.w), ldw, T, hid, E, h, hid);
+                if (s1) gp_seg2(g, s1, E, W(lp.w) + E, ldw, E);
+            } else {
+                g = gp_make(hbuf[j - 1], hid, W(lp.w), hid, T, hid, hid, h, hid);
+            }
+            g.bias = W(lp.b); g.flags |= GF_RELU_OUT; g.drop_site = s;
+            chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+            hbuf.push_back(h);
+            hsite.push_back(s);
+        }
+        float* logits = ar.f((size_t)T * C);
+        P.bufs[M2F_BUF_LOGITS] = logits;
+        {
+            const LinP& lp = P.pm.cls[nhid];
+            GemmProblem g = gp_make(hbuf[nhid - 1], hid, W(lp.w), hid, T, C, hid, logits, C);
+            g.bias = W(lp.b);
+            chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
+        }
+        float* dlogits = ar.f((size_t)T * C);
+        P.bufs[M2F_BUF_DLOGITS] = dlogits;
+        P.loss_terms = ar.f((size_t)T * 2);
+        P.bufs[M2F_BUF_LOSS] = ar.f(4);
+        if (!P.train) return;
+
+        // ------------------------------ backward -----------------------------------------------------
+        const float gs = gscale();
+        {   // last linear
+            const LinP& lp = P.pm.cls[nhid];
+            wgrad(dlogits, C, hbuf[nhid - 1], hid, C, hid, lp.w, hid, (long)lp.b);
+        }
+        float* dh = ar.f((size_t)T * hid);
+        {
+            const LinP& lp = P.pm.cls[nhid];
+            GemmProblem g = gp_make(dlogits, C, W(lp.w), hid, T, hid, C, dh, hid);
+            g.gate = hbuf[nhid - 1]; g.ldgate = hid; g.gate_scale = hsite[nhid - 1] ? gs : 1.f;
+            chain_b.push_back(op_gemm(M2F_LAYOUT_NN, g));
+        }
+        for (int j = nhid - 1; j >= 1; --j) {
+            const LinP& lp = P.pm.cls[j];
+            wgrad(dh, hid, hbuf[j - 1], hid, hid, hid, lp.w, hid, (long)lp.b);
+            float* dprev = ar.f((size_t)T * hid);
+            GemmProblem g = gp_make(dh, hid, W(lp.w), hid, T, hid, hid, dprev, hid);
+            g.gate = hbuf[j - 1]; g.ldgate = hid; g.gate_scale = 1.f;
+            chain_b.push_back(op_gemm(M2F_LAYOUT_NN, g));
+            dh = dprev;
+        }
+        // Linear0: input = cat(a, t) | t | a
+        const LinP& l0 = P.pm.cls[0];
+        const int ldw0 = cls_in_width(c);
+        float* d_a = a_on ? ar.f((size_t)T * E) : nullptr;
+        float* d_t = t_on ? ar.f((size_t)T * E) : nullptr;
+        {
+            Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NN;
+            if (a_on && t_on) {
+                wgrad(dh, hid, a, E, hid, E, l0.w, ldw0, (long)l0.b);
+                wgrad(dh, hid, t, E, hid, E, l0.w + E, ldw0, -1);
+                o.gp.push_back(gp_make(dh, hid, W(l0.w), ldw0, T, E, hid, d_a, E));
+                GemmProblem g = gp_make(dh, hid, W(l0.w) + E, ldw0, T, E, hid, d_t, E);
+                if (c.fam_enabled) { g.gate = t; g.ldgate = E; g.gate_scale = fam.back().site_out ? gs : 1.f; }
+                o.gp.push_back(g);
+            } else {
+                const float* x = t_on ? t : a;
+                float* dx = t_on ? d_t : d_a;
+                wgrad(dh, hid, x, E, hid, E, l0.w, ldw0, (long)l0.b);
+                o.gp.push_back(gp_make(dh, hid, W(l0.w), ldw0, T, E, hid, dx, E));
+            }
+            chain_b.push_back(o);
+        }
+        // fusion layers, last to first.  `dz` = gradient w.r.t. the pre-ReLU output of layer i (the
+        // ReLU/dropout gate was applied by the producer's epilogue).
+        const float* dz = d_t;
+        for (int i = (int)fam.size() - 1; i >= 0; --i) {
+            const FamP& p = P.pm.fam[i];
+            const FamBuf& b = fam[i];
+            wgrad(dz, E, b.x, E, E, E, p.lin_w, 2 * E, (long)p.lin_b, true);
+            wgrad(dz, E, b.t_in, E, E, E, p.lin_w + E, 2 * E, -1, true);
+            float* dx = ar.f((size_t)T * E);
+            float* dtA = ar.f((size_t)T * E);
+            {
+                Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NN;
+                GemmProblem g1 = gp_make(dz, E, W(p.lin_w), 2 * E, T, E, E, dx, E);
+                g1.gate = b.x; g1.ldgate = E;
+                GemmProblem g2 = gp_make(dz, E, W(p.lin_w) + E, 2 * E, T, E, E, dtA, E);
+                g2.gate = b.t_in; g2.ldgate = E;
+                o.gp.push_back(g1); o.gp.push_back(g2);
+                chain_b.push_back(o);
+            }
+            wgrad(dx, E, b.att, E, E, E, p.out_w, E, (long)p.out_b);
+            float* datt = ar.f((size_t)T * E);
+            chain_b.push_back(op_gemm(M2F_LAYOUT_NN, gp_make(dx, E, W(p.out_w), E, T, E, E, datt, E)));
+            float* dqv = ar.f((size_t)T * 2 * E);
+            float* dk = ar.f((size_t)T * E);
+            {
+                Op o; o.kind = OP_ATTN_BWD;
+                AttnProblem at; memset(&at, 0, sizeof(at));
+                at.q = b.qv; at.ldq = 2 * E; at.k = b.k; at.ldk = E; at.v = b.qv + E; at.ldv = 2 * E;
+                at.out = b.att; at.ldo = E; at.probs = b.probs; at.H = Hf; at.hd = E / Hf; at.drop_site = b.site_attn;
+                at.dout = datt; at.lddo = E;
+                at.dq = dqv; at.lddq = 2 * E; at.dv = dqv + E; at.lddv = 2 * E; at.dk = dk; at.lddk = E;
+                o.ap.push_back(at);
+                chain_b.push_back(o);
+            }
+            wgrad(dqv, 2 * E, b.t_in, E, E, E, p.in_w, E, (long)p.in_b);                                        // dWq, dbq
+            wgrad(dk, E, a, E, E, E, p.in_w + (size_t)E * E, E, (long)(p.in_b + E));                            // dWk, dbk
+            wgrad(dqv + E, 2 * E, b.t_in, E, E, E, p.in_w + (size_t)2 * E * E, E, (long)(p.in_b + 2 * E));      // dWv, dbv
+            float* dt = ar.f((size_t)T * E);
+            {
+                Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NN;
+                // d t_in = dq Wq + dv Wv + dtA   (then the previous layer's ReLU/dropout gate)
+                GemmProblem g = gp_make(dqv, 2 * E, W(p.in_w), E, T, E, E, dt, E);
+                gp_seg2(g, dqv + E, 2 * E, W(p.in_w + (size_t)2 * E * E), E, E);
+                g.res = dtA; g.ldres = E;
+                if (i > 0) { g.gate = b.t_in; g.ldgate = E; g.gate_scale = fam[i - 1].site_out ? gs : 1.f; }
+                // d audio += dk Wk
+                GemmProblem ga = gp_make(dk, E, W(p.in_w + (size_t)E * E), E, T, E, E, d_a, E);
+                ga.flags |= GF_ACCUM;
+                o.gp.push_back(g); o.gp.push_back(ga);
+                chain_b.push_back(o);
+            }
+            dz = dt;
+        }
+        d_t = const_cast<float*>(dz);
+        // gradient through the post-projection dropout (src/model.py:113,125)
+        for (int bi = 0; bi < 2; ++bi) {
+            float* dxp = bi == 0 ? d_a : d_t;
+            if (!dxp) continue;
+            if (mod[bi].site_post) {
+                Op o; o.kind = OP_DROPOUT; o.dptr = dxp; o.dT = T; o.dd = E; o.dld = E; o.dsite = mod[bi].site_post;
+                chain_b.push_back(o);
+            }
+            build_modality_bwd(bi, bi == 0 ? P.pm.audio : P.pm.text, dxp);
+        }
+    }
+};
+
+// ---- merge two independent op chains into grouped launches (LCS on compatibility) -------------------
+bool compatible(const Op& a, const Op& b) {
+    if (a.kind != b.kind) return false;
+    switch (a.kind) {
+        case OP_GEMM: return a.layout == b.layout && a.gp.size() + b.gp.size() <= M2F_GEMM_MAX_PROBLEMS;
+        case OP_ATTN_FWD: case OP_ATTN_BWD: return a.ap.size() + b.ap.size() <= M2F_ATTN_MAX_PROBLEMS;
+        case OP_LN_FWD: case OP_LN_BWD: return a.lp.size() + b.lp.size() <= M2F_LN_MAX_PROBLEMS;
+        default: return false;
+    }
+}
+Op merged(const Op& a, const Op& b) {
+    Op o = a;
+    o.gp.insert(o.gp.end(), b.gp.begin(), b.gp.end());
+    o.ap.insert(o.ap.end(), b.ap.begin(), b.ap.end());
+    o.lp.insert(o.lp.end(), b.lp.begin(), b.lp.end());
+    return o;
+}
+std::vector<Op> merge_chains(const std::vector<Op>& A, const std::vector<Op>& B) {
+    const size_t n = A.size(), m = B.size();
+    if (n == 0) return B;
+    if (m == 0) return A;
+    std::vector<std::vector<int>> dp(n + 1, std::vector<int>(m + 1, 0));
+    for (size_t i = n; i-- > 0;)
+        for (size_t j = m; j-- > 0;) {
+            int best = std::max(dp[i + 1][j], dp[i][j + 1]);
+            if (compatible(A[i], B[j])) best = std::max(best, dp[i + 1][j + 1] + 1);
+            dp[i][j] = best;
+        }
+    std::vector<Op> out;
+    size_t i = 0, j = 0;
+    while (i < n && j < m) {
+        if (compatible(A[i], B[j]) && dp[i][j] == dp[i + 1][j + 1] + 1) { out.push_back(merged(A[i], B[j])); ++i; ++j; }
+        else if (dp[i + 1][j] >= dp[i][j + 1]) out.push_back(A[i++]);
+        else out.push_back(B[j++]);
+    }
+    while (i < n) out.push_back(A[i++]);
+    while (j < m) out.push_back(B[j++]);
+    return out;
+}
+
+void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Launch>& out) {
+    for (const Op& o : ops) {
+        Launch l;
+        l.kind = o.kind; l.layout = o.layout;
+        memset(&l.gb, 0, sizeof(l.gb)); memset(&l.ab, 0, sizeof(l.ab)); memset(&l.lb, 0, sizeof(l.lb));
+        switch (o.kind) {
+            case OP_GEMM:
+                l.gb.count = (int)o.gp.size();
+                for (size_t i = 0; i < o.gp.size(); ++i) l.gb.pr[i] = o.gp[i];
+                l.gb.rng = P.rng; l.gb.drop_thresh = P.drop_thresh; l.gb.drop_scale = P.drop_scale;
+                break;
+            case OP_ATTN_FWD: case OP_ATTN_BWD:
+                l.ab.count = (int)o.ap.size();
+                for (size_t i = 0; i < o.ap.size(); ++i) l.ab.pr[i] = o.ap[i];
+                l.ab.B = P.B; l.ab.L = P.L; l.ab.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
+                l.ab.rng = P.rng; l.ab.drop_thresh = P.drop_thresh; l.ab.drop_scale = P.drop_scale;
+                break;
+            case OP_LN_FWD: case OP_LN_BWD:
+                l.lb.count = (int)o.lp.size();
+                for (size_t i = 0; i < o.lp.size(); ++i) l.lb.pr[i] = o.lp[i];
+                l.lb.T = P.T; l.lb.eps = P.cfg.ln_eps;
+                l.lb.rng = P.rng; l.lb.drop_thresh = P.drop_thresh; l.lb.drop_scale = P.drop_scale;
+                break;
+            case OP_DROPOUT:
+                l.dptr = o.dptr; l.dT = o.dT; l.dd = o.dd; l.dld = o.dld; l.dsite = o.dsite;
+                break;
+        }
+        out.push_back(l);
+    }
+}
+
+int build_plan(m2f_plan& P, char* ws_base) {
+    const m2f_config& c = P.cfg;
+    Builder bld(P);
+    bld.ar.base = ws_base;
+    const int T = P.T;
+    // host-visible input staging
+    P.bufs[M2F_BUF_TEXT] = bld.ar.f((size_t)T * std::max(c.d_text, 1));
+    P.bufs[M2F_BUF_AUDIO] = bld.ar.f((size_t)T * std::max(c.d_audio, 1));
+    P.bufs[M2F_BUF_KEYPAD] = bld.ar.alloc<uint8_t>((size_t)T);
+    P.bufs[M2F_BUF_LABELS] = bld.ar.alloc<int64_t>((size_t)T);
+    P.bufs[M2F_BUF_CLASSW] = bld.ar.f(16);
+    if (c.audio_enabled)
+        bld.build_modality(0, P.pm.audio, c.d_audio, c.nhead_audio, c.nlayers_audio, c.ntrans_audio,
+                           static_cast<const float*>(P.bufs[M2F_BUF_AUDIO]));
+    if (c.text_enabled)
+        bld.build_modality(1, P.pm.text, c.d_text, c.nhead_text, c.nlayers_text, c.ntrans_text,
+                           static_cast<const float*>(P.bufs[M2F_BUF_TEXT]));
+    bld.build_head();
+    // forward: merged branches, then fusion + classifier
+    to_launches(P, merge_chains(bld.br_f[0], bld.br_f[1]), P.fwd);
+    to_launches(P, bld.chain_f, P.fwd);
+    if (P.train) {
+        to_launches(P, bld.chain_b, P.bwd);
+        to_launches(P, merge_chains(bld.br_b[0], bld.br_b[1]), P.bwd);
+        // deferred weight gradients: chip-filling grouped launches
+        std::vector<Op> wops;
+        for (size_t i = 0; i < bld.wgrads.size(); i += M2F_GEMM_MAX_PROBLEMS) {
+            Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
+            for (size_t j = i; j < std::min(bld.wgrads.size(), i + M2F_GEMM_MAX_PROBLEMS); ++j) o.gp.push_back(bld.wgrads[j]);
+            wops.push_back(o);
+        }
+        to_launches(P, wops, P.bwd);
+        for (size_t i = 0; i < bld.lnitems.size(); i += M2F_LNRED_MAX_ITEMS) {
+            LnReduceBatch rb;
+            memset(&rb, 0, sizeof(rb));
+            for (size_t j = i; j < std::min(bld.lnitems.size(), i + M2F_LNRED_MAX_ITEMS); ++j) rb.it[rb.count++] = bld.lnitems[j];
+            P.lnred.push_back(rb);
+        }
+    }
+    P.ws_used = bld.ar.off;
+    return 0;
+}
+
+int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s) {
+    for (Launch& l : ls) {
+        hipError_t e = hipSuccess;
+        switch (l.kind) {
+            case OP_GEMM: e = m2f_launch_gemm(l.gb, P.prec, l.layout, 0, s); break;
+            case OP_ATTN_FWD: e = m2f_launch_attn_fwd(l.ab, s); break;
+            case OP_ATTN_BWD: e = m2f_launch_attn_bwd(l.ab, s); break;
+            case OP_LN_FWD: e = m2f_launch_ln_fwd(l.lb, s); break;
+            case OP_LN_BWD: e = m2f_launch_ln_bwd(l.lb, s); break;
+            case OP_DROPOUT: e = m2f_launch_dropout_inplace(l.dptr, l.dT, l.dd, l.dld, l.dsite, P.rng, P.drop_thresh, P.drop_scale, s); break;
+        }
+        if (e != hipSuccess) return hipfail(e, "kernel launch");
+    }
+    return 0;
+}
+
+int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
+    CeArgs a;
+    a.logits = static_cast<const float*>(P.bufs[M2F_BUF_LOGITS]);
+    a.T = P.T; a.C = P.cfg.cls_out;
+    a.labels = static_cast<const int64_t*>(P.bufs[M2F_BUF_LABELS]);
+    a.class_w = use_cw ? static_cast<const float*>(P.bufs[M2F_BUF_CLASSW]) : nullptr;
+    a.label_smoothing = ls;
+    a.loss_terms = P.loss_terms;
+    a.dlogits = static_cast<float*>(P.bufs[M2F_BUF_DLOGITS]);
+    M2F_HIP(m2f_launch_ce(a, s));
+    M2F_HIP(m2f_launch_loss_finalize(P.loss_terms, P.T, P.cfg.cls_out, a.dlogits, static_cast<float*>(P.bufs[M2F_BUF_LOSS]), normalise, s));
+    return 0;
+}
+
+int do_backward(m2f_plan& P, hipStream_t s) {
+    if (!P.train || !P.grads) return fail("m2f_backward: plan was created without train=1 / gradient buffer");
+    if (int r = run_launches(P, P.bwd, s)) return r;
+    for (const LnReduceBatch& rb : P.lnred) M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* m2f_last_error(void) { return g_err.c_str(); }
+
+int m2f_device_check(void) {
+    int dev = 0;
+    M2F_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    M2F_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(std::string("not a gfx950 device: ") + prop.gcnArchName);
+    return 0;
+}
+
+int m2f_param_layout(const m2f_config* cfg, int64_t* offsets, int64_t* numels, int max_entries, int64_t* total) {
+    ParamMap pm;
+    if (build_param_map(*cfg, pm)) return -1;
+    const int n = (int)pm.offsets.size();
+    for (int i = 0; i < n && i < max_entries; ++i) { offsets[i] = pm.offsets[i]; numels[i] = pm.numels[i]; }
+    if (total) *total = (int64_t)pm.total;
+    return n;
+}
+
+static m2f_plan* plan_new(const m2f_config* cfg, int B, int L, int precision, int train) {
+    if (B < 1 || L < 1 || L > 64) { fail("B >= 1 and 1 <= L <= 64 required (L = utterances per dialogue)"); return nullptr; }
+    if (precision != M2F_F32 && precision != M2F_BF16) { fail("bad precision"); return nullptr; }
+    m2f_plan* p = new m2f_plan();
+    p->cfg = *cfg;
+    p->B = B; p->L = L; p->T = B * L; p->prec = precision; p->train = train;
+    if (build_param_map(*cfg, p->pm)) { delete p; return nullptr; }
+    if ((cfg->audio_enabled && (cfg->nlayers_audio < 1 || cfg->ntrans_audio < 1)) ||
+        (cfg->text_enabled && (cfg->nlayers_text < 1 || cfg->ntrans_text < 1)) ||
+        (cfg->fam_enabled && cfg->nlayers_fam < 1)) {
+        fail("layer / transformer counts must be >= 1");
+        delete p;
+        return nullptr;
+    }
+    p->use_dropout = train && cfg->dropout > 0.f;
+    if (p->use_dropout) {
+        p->drop_thresh = (uint32_t)std::min(4294967295.0, std::floor((double)cfg->dropout * 4294967296.0));
+        p->drop_scale = 1.0f / (1.0f - cfg->dropout);
+    }
+    return p;
+}
+
+int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train) {
+    m2f_plan* p = plan_new(cfg, B, L, M2F_F32, train);
+    if (!p) return -1;
+    p->params = nullptr; p->grads = nullptr;
+    build_plan(*p, nullptr);
+    const int64_t n = (int64_t)p->ws_used + 4096;
+    delete p;
+    return n;
+}
+
+m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, int train, float* params, float* grads,
+                          void* workspace, int64_t workspace_bytes, uint32_t* rng_state) {
+    m2f_plan* p = plan_new(cfg, B, L, precision, train);
+    if (!p) return nullptr;
+    if (!params || !workspace) { fail("params / workspace must not be NULL"); delete p; return nullptr; }
+    if (train && !grads) { fail("train plan needs a gradient buffer"); delete p; return nullptr; }
+    if (p->use_dropout && !rng_state) { fail("dropout > 0 in train mode needs an rng_state"); delete p; return nullptr; }
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(params) & 255) ||
+        (grads && (reinterpret_cast<uintptr_t>(grads) & 255))) {
+        fail("params / grads / workspace must be 256-byte aligned"); delete p; return nullptr;
+    }
+    p->params = params; p->grads = grads; p->rng = rng_state;
+    build_plan(*p, static_cast<char*>(workspace));
+    if ((int64_t)p->ws_used > workspace_bytes) {
+        fail("workspace too small: need " + std::to_string(p->ws_used) + " bytes");
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+void m2f_plan_destroy(m2f_plan* plan) { delete plan; }
+
+void* m2f_plan_buffer(m2f_plan* plan, int which) {
+    if (!plan || which < 0 || which >= M2F_BUF_COUNT) return nullptr;
+    return plan->bufs[which];
+}
+
+int m2f_plan_num_launches(m2f_plan* plan, int phase) {
+    if (phase == 0) return (int)plan->fwd.size();
+    if (phase == 1) return 2;
+    return (int)(plan->bwd.size() + plan->lnred.size());
+}
+
+int m2f_forward(m2f_plan* plan, m2f_stream_t stream) {
+    return run_launches(*plan, plan->fwd, static_cast<hipStream_t>(stream));
+}
+
+int m2f_loss(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream) {
+    return do_loss(*plan, label_smoothing, use_class_weights, normalise, static_cast<hipStream_t>(stream));
+}
+
+int m2f_backward(m2f_plan* plan, m2f_stream_t stream) { return do_backward(*plan, static_cast<hipStream_t>(stream)); }
+
+static int step_body(m2f_plan& P, float ls, int cw, int normalise, hipStream_t s) {
+    if (P.use_dropout) M2F_HIP(m2f_launch_rng_advance(P.rng, s));
+    if (int r = run_launches(P, P.fwd, s)) return r;
+    if (int r = do_loss(P, ls, cw, normalise, s)) return r;
+    return do_backward(P, s);
+}
+
+int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, int use_graph,
+             m2f_stream_t stream) {
+    m2f_plan& P = *plan;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!P.train) return fail("m2f_step needs a train plan");
+    if (!use_graph || !P.warmed) { P.warmed = true; return step_body(P, label_smoothing, use_class_weights, normalise, s); }
+    if (P.gexec && (P.g_ls != label_smoothing || P.g_cw != use_class_weights || P.g_norm != normalise)) {
+        (void)hipGraphExecDestroy(P.gexec);
+        P.gexec = nullptr;
+    }
+    if (!P.gexec) {
+        hipGraph_t graph = nullptr;
+        M2F_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int r = step_body(P, label_smoothing, use_class_weights, normalise, s);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+        if (e != hipSuccess) return hipfail(e, "hipStreamEndCapture");
+        e = hipGraphInstantiate(&P.gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { P.gexec = nullptr; return hipfail(e, "hipGraphInstantiate"); }
+        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise;
+    }
+    M2F_HIP(hipGraphLaunch(P.gexec, s));
+    return 0;
+}
+
+int m2f_rng_advance(uint32_t* rng_state, m2f_stream_t stream) {
+    M2F_HIP(m2f_launch_rng_advance(rng_state, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr, m2f_stream_t stream) {
+    M2F_HIP(m2f_launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale_ptr,
+                            static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// ---- kernel-level entry points -----------------------------------------------------------------------
+static void drop_params(float p, uint32_t* thresh, float* scale) {
+    *thresh = (uint32_t)std::min(4294967295.0, std::floor((double)p * 4294967296.0));
+    *scale = 1.0f / (1.0f - p);
+}
+
+int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const float* a0, int lda0, const float* a1, int lda1,
+             const float* b0, int ldb0, const float* b1, int ldb1, float* c, int ldc, const float* bias, const float* res,
+             int ldres, const float* gate, int ldgate, float gate_scale, float* bias_grad, int relu_a, int relu_b,
+             int relu_out, int accumulate, uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile,
+             m2f_stream_t stream) {
+    GemmBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    GemmProblem p = gp_make(a0, lda0, b0, ldb0, M, N, K0, c, ldc);
+    if (K1 > 0) gp_seg2(p, a1, lda1, b1, ldb1, K1);
+    p.bias = bias; p.res = res; p.ldres = ldres; p.gate = gate; p.ldgate = ldgate; p.gate_scale = gate_scale;
+    p.bias_grad = bias_grad; p.drop_site = drop_site;
+    p.flags = (relu_a ? GF_RELU_A : 0) | (relu_b ? GF_RELU_B : 0) | (relu_out ? GF_RELU_OUT : 0) | (accumulate ? GF_ACCUM : 0);
+    gb.pr[0] = p; gb.count = 1; gb.rng = rng_state;
+    if (drop_site) drop_params(drop_p, &gb.drop_thresh, &gb.drop_scale);
+    M2F_HIP(m2f_launch_gemm(gb, precision, layout, tile, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+static void attn_fill(AttnBatch& ab, int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk,
+                      const float* v, int ldv, const uint8_t* key_pad, float* out, int ldo, float* probs, uint32_t drop_site,
+                      float drop_p, const uint32_t* rng_state) {
+    memset(&ab, 0, sizeof(ab));
+    AttnProblem& p = ab.pr[0];
+    p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.out = out; p.ldo = ldo; p.probs = probs;
+    p.H = H; p.hd = hd; p.drop_site = drop_site;
+    ab.count = 1; ab.B = B; ab.L = L; ab.key_pad = key_pad; ab.rng = rng_state;
+    ab.drop_scale = 1.f;
+    if (drop_site) drop_params(drop_p, &ab.drop_thresh, &ab.drop_scale);
+}
+
+int m2f_attention_fwd(int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                      const uint8_t* key_pad, float* out, int ldo, float* probs, uint32_t drop_site, float drop_p,
+                      const uint32_t* rng_state, m2f_stream_t stream) {
+    AttnBatch ab;
+    attn_fill(ab, B, L, H, hd, q, ldq, k, ldk, v, ldv, key_pad, out, ldo, probs, drop_site, drop_p, rng_state);
+    M2F_HIP(m2f_launch_attn_fwd(ab, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_attention_bwd(int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                      const uint8_t* key_pad, const float* out, int ldo, const float* probs, const float* dout, int lddo,
+                      float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, uint32_t drop_site, float drop_p,
+                      const uint32_t* rng_state, m2f_stream_t stream) {
+    AttnBatch ab;
+    attn_fill(ab, B, L, H, hd, q, ldq, k, ldk, v, ldv, key_pad, const_cast<float*>(out), ldo, const_cast<float*>(probs),
+              drop_site, drop_p, rng_state);
+    AttnProblem& p = ab.pr[0];
+    p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    M2F_HIP(m2f_launch_attn_bwd(ab, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int64_t m2f_attention_probs_elems(int B, int H, int L) { return (int64_t)m2f_attn_probs_elems(B, H, L); }
+
+int m2f_layernorm_fwd(int T, int d, const float* x, const float* gamma, const float* beta, const float* res, float* out,
+                      float* stats, float eps, m2f_stream_t stream) {
+    LnBatch lb;
+    memset(&lb, 0, sizeof(lb));
+    LnProblem& p = lb.pr[0];
+    p.x = x; p.gamma = gamma; p.beta = beta; p.res = res; p.out = out; p.stats = stats; p.d = d;
+    lb.count = 1; lb.T = T; lb.eps = eps; lb.drop_scale = 1.f;
+    M2F_HIP(m2f_launch_ln_fwd(lb, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_layernorm_bwd(int T, int d, const float* x, const float* gamma, const float* stats, const float* dy, const float* extra,
+                      float* dx, float* partial, float* dgamma, float* dbeta, m2f_stream_t stream) {
+    LnBatch lb;
+    memset(&lb, 0, sizeof(lb));
+    LnProblem& p = lb.pr[0];
+    p.x = x; p.gamma = gamma; p.stats = const_cast<float*>(stats); p.dy = dy; p.extra = extra; p.dx = dx; p.partial = partial; p.d = d;
+    lb.count = 1; lb.T = T; lb.eps = 0.f; lb.drop_scale = 1.f;
+    M2F_HIP(m2f_launch_ln_bwd(lb, static_cast<hipStream_t>(stream)));
+    LnReduceBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    rb.it[0].partial = partial; rb.it[0].dgamma = dgamma; rb.it[0].dbeta = dbeta; rb.it[0].d = d; rb.it[0].nblk = m2f_ln_row_blocks(T);
+    rb.count = 1;
+    M2F_HIP(m2f_launch_ln_param_reduce(rb, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_cross_entropy(int T, int C, const float* logits, const int64_t* labels, const float* class_w, float label_smoothing,
+                      int normalise, float* loss_terms, float* dlogits, float* loss_out, m2f_stream_t stream) {
+    CeArgs a;
+    a.logits = logits; a.T = T; a.C = C; a.labels = labels; a.class_w = class_w; a.label_smoothing = label_smoothing;
+    a.loss_terms = loss_terms; a.dlogits = dlogits;
+    M2F_HIP(m2f_launch_ce(a, static_cast<hipStream_t>(stream)));
+    M2F_HIP(m2f_launch_loss_finalize(loss_terms, T, C, dlogits, loss_out, normalise, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+}  // extern "C"

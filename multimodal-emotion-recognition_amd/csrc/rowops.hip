@@ -1,0 +1,384 @@
+// Row-wise (HBM-bound) kernels of the M2FNet step for gfx950: LayerNorm forward/backward with fused
+// residual / dropout, the label-smoothed cross-entropy criterion (reference src/train.py:48-50), the
+// dropout-mask re-application used in backward, and the fused Adam update (src/train.py:56).
+// One wavefront per token row, rows cached in registers, 16-byte coalesced accesses, wave shuffles for
+// the row reductions; column reductions (dgamma/dbeta) go through per-block partials (deterministic,
+// no atomics, no memset).
+#include "common.h"
+#include "ops.h"
+
+namespace {
+
+constexpr int LN_MAXV_LIMIT = 8;           // float4 chunks per lane  -> d <= 2048 (kernels templated on NV)
+constexpr int LN_WAVES = 4;
+constexpr int LN_ROWS_PER_WAVE = M2F_LN_ROWS_PER_BLOCK / LN_WAVES;
+
+template <int NV> struct RowRegs { f32x4 v[NV]; };
+
+// lane owns elements c = 4*(lane + 64*j) .. +3 ; scalar tail handling when d % 4 != 0 or unaligned.
+template <int NV>
+__device__ __forceinline__ void row_load(RowRegs<NV>& r, const float* __restrict__ p, int d, bool vec, int lane) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (c < d) {
+            if (vec) x = *reinterpret_cast<const f32x4*>(p + c);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < d) x[e] = p[c + e];
+            }
+        }
+        r.v[j] = x;
+    }
+}
+template <int NV>
+__device__ __forceinline__ void row_store(const RowRegs<NV>& r, float* __restrict__ p, int d, bool vec, int lane) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < d) {
+            if (vec) *reinterpret_cast<f32x4*>(p + c) = r.v[j];
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < d) p[c + e] = r.v[j][e];
+            }
+        }
+    }
+}
+__device__ __forceinline__ bool is_vec(const void* p, int d) {
+    return ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < M2F_LN_MAX_PROBLEMS; ++i)
+        if (i < lb.count && (int)blockIdx.x >= lb.pr[i].block_begin) pi = i;
+    const LnProblem& P = lb.pr[pi];
+    const int d = P.d;
+    const int blk = (int)blockIdx.x - P.block_begin;
+    const bool vec = is_vec(P.x, d) && is_vec(P.out, d) && is_vec(P.gamma, d) && is_vec(P.beta, d) &&
+                     (!P.res || is_vec(P.res, d));
+    RowRegs<NV> g, be;
+    row_load(g, P.gamma, d, vec, lane);
+    row_load(be, P.beta, d, vec, lane);
+    uint32_t key = 0;
+    if (P.drop_site) key = m2f_site_key(lb.rng, P.drop_site);
+    const float invd = 1.0f / (float)d;
+    for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+        const int row = blk * M2F_LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE + rr;
+        if (row >= lb.T) break;                             // wave-uniform
+        RowRegs<NV> x;
+        row_load(x, P.x + (size_t)row * d, d, vec, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (x.v[j][0] + x.v[j][1]) + (x.v[j][2] + x.v[j][3]);
+        const float mean = m2f_wave_sum(s) * invd;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * (lane + 64 * j) + e;
+                const float t = (c < d) ? x.v[j][e] - mean : 0.f;
+                q += t * t;
+            }
+        const float rstd = 1.0f / sqrtf(m2f_wave_sum(q) * invd + lb.eps);
+        RowRegs<NV> res;
+        if (P.res) row_load(res, P.res + (size_t)row * d, d, vec, lane);
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = (x.v[j][e] - mean) * rstd * g.v[j][e] + be.v[j][e];
+                if (P.res) y += res.v[j][e];
+                if (P.drop_site) {
+                    const int c = 4 * (lane + 64 * j) + e;
+                    y = m2f_keep(key, (uint32_t)row * (uint32_t)d + (uint32_t)c, lb.drop_thresh) ? y * lb.drop_scale : 0.f;
+                }
+                x.v[j][e] = y;
+            }
+        row_store(x, P.out + (size_t)row * d, d, vec, lane);
+        if (lane == 0) { P.stats[2 * row] = mean; P.stats[2 * row + 1] = rstd; }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [LN_WAVES][2][dpad]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < M2F_LN_MAX_PROBLEMS; ++i)
+        if (i < lb.count && (int)blockIdx.x >= lb.pr[i].block_begin) pi = i;
+    const LnProblem& P = lb.pr[pi];
+    const int d = P.d;
+    const int dpad = (d + 3) & ~3;
+    const int blk = (int)blockIdx.x - P.block_begin;
+    const bool vec = is_vec(P.x, d) && is_vec(P.dy, d) && is_vec(P.dx, d) && is_vec(P.gamma, d) &&
+                     (!P.extra || is_vec(P.extra, d)) && (!P.dx_masked || is_vec(P.dx_masked, d));
+    RowRegs<NV> g, dg, db;
+    row_load(g, P.gamma, d, vec, lane);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { dg.v[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; db.v[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    uint32_t key = 0;
+    if (P.drop_site2) key = m2f_site_key(lb.rng, P.drop_site2);
+    const float invd = 1.0f / (float)d;
+    for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+        const int row = blk * M2F_LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE + rr;
+        if (row >= lb.T) break;
+        RowRegs<NV> x, dy;
+        row_load(x, P.x + (size_t)row * d, d, vec, lane);
+        row_load(dy, P.dy + (size_t)row * d, d, vec, lane);
+        const float mean = P.stats[2 * row], rstd = P.stats[2 * row + 1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * (lane + 64 * j) + e;
+                const float xh = (c < d) ? (x.v[j][e] - mean) * rstd : 0.f;
+                const float gy = dy.v[j][e] * g.v[j][e];
+                x.v[j][e] = xh;
+                s1 += gy;
+                s2 += gy * xh;
+                dg.v[j][e] += dy.v[j][e] * xh;
+                db.v[j][e] += dy.v[j][e];
+            }
+        const float c1 = m2f_wave_sum(s1) * invd, c2 = m2f_wave_sum(s2) * invd;
+        RowRegs<NV> ex;
+        if (P.extra) row_load(ex, P.extra + (size_t)row * d, d, vec, lane);
+        RowRegs<NV> msk;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dx = rstd * (dy.v[j][e] * g.v[j][e] - c1 - x.v[j][e] * c2);
+                float dm = dx;
+                if (P.drop_site2) {
+                    const int c = 4 * (lane + 64 * j) + e;
+                    dm = m2f_keep(key, (uint32_t)row * (uint32_t)d + (uint32_t)c, lb.drop_thresh) ? dx * lb.drop_scale : 0.f;
+                }
+                msk.v[j][e] = dm;
+                dy.v[j][e] = P.extra ? dx + ex.v[j][e] : dx;
+            }
+        row_store(dy, P.dx + (size_t)row * d, d, vec, lane);
+        if (P.dx_masked) row_store(msk, P.dx_masked + (size_t)row * d, d, vec, lane);
+    }
+    // per-block partial dgamma / dbeta: waves -> LDS -> fixed-order sum (deterministic)
+    float* mine = red + (size_t)wave * 2 * dpad;
+    row_store(dg, mine, dpad, true, lane);
+    row_store(db, mine + dpad, dpad, true, lane);
+    __syncthreads();
+    float* out = P.partial + (size_t)blk * 2 * d;
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        const int which = c >= d, cc = which ? c - d : c;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < LN_WAVES; ++w) s += red[(size_t)w * 2 * dpad + which * dpad + cc];
+        out[c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void m2f_ln_param_reduce_kernel(const LnReduceBatch rb) {
+    const LnReduceItem& it = rb.it[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= it.d) return;
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < it.nblk; ++b) {
+        sg += it.partial[(size_t)b * 2 * it.d + c];
+        sb += it.partial[(size_t)b * 2 * it.d + it.d + c];
+    }
+    it.dgamma[c] = sg;
+    it.dbeta[c] = sb;
+}
+
+// ---- criterion ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void m2f_ce_kernel(const CeArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.T) return;
+    const int C = a.C;
+    float z[16], w[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        z[c] = (c < C) ? a.logits[(size_t)t * C + c] : -INFINITY;
+        w[c] = (c < C) ? (a.class_w ? a.class_w[c] : 1.f) : 0.f;
+        m = fmaxf(m, z[c]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) se += (c < C) ? expf(z[c] - m) : 0.f;
+    const float lse = m + logf(se);
+    const int64_t y = a.labels[t];
+    const bool valid = (y >= 0) && (y < C);
+    float wy = 0.f, logpy = 0.f, W = 0.f, sm = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < C) {
+            const float lp = z[c] - lse;
+            W += w[c];
+            sm -= w[c] * lp;
+            if (valid && c == (int)y) { wy = w[c]; logpy = lp; }
+        }
+    }
+    const float eps = a.label_smoothing;
+    const float num = valid ? ((1.f - eps) * (-logpy) * wy + eps * sm / (float)C) : 0.f;
+    a.loss_terms[2 * t] = num;
+    a.loss_terms[2 * t + 1] = valid ? wy : 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < C) {
+            const float p = expf(z[c] - lse);
+            float g = 0.f;
+            if (valid) g = (1.f - eps) * wy * (p - ((c == (int)y) ? 1.f : 0.f)) + (eps / (float)C) * (W * p - w[c]);
+            a.dlogits[(size_t)t * C + c] = g;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void m2f_loss_finalize_kernel(const float* __restrict__ terms, int T, int C,
+                                                                float* __restrict__ dlogits, float* __restrict__ loss_out,
+                                                                int normalise) {
+    __shared__ float sn[4], sd[4];
+    float n = 0.f, dd = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { n += terms[2 * t]; dd += terms[2 * t + 1]; }
+    n = m2f_wave_sum(n);
+    dd = m2f_wave_sum(dd);
+    if ((threadIdx.x & 63) == 0) { sn[threadIdx.x >> 6] = n; sd[threadIdx.x >> 6] = dd; }
+    __syncthreads();
+    const float num = (sn[0] + sn[1]) + (sn[2] + sn[3]);
+    const float den = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+    if (threadIdx.x == 0) { loss_out[0] = num / den; loss_out[1] = den; loss_out[2] = num; }
+    if (normalise) {
+        const float inv = 1.0f / den;
+        for (int e = threadIdx.x; e < T * C; e += 256) dlogits[e] *= inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void m2f_dropout_inplace_kernel(float* __restrict__ x, int T, int d, int ld, uint32_t site,
+                                                                  const uint32_t* __restrict__ rng, uint32_t thresh, float scale) {
+    const uint32_t key = m2f_site_key(rng, site);
+    const size_t n = (size_t)T * d;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / d), c = (int)(e - (size_t)r * d);
+        float* p = x + (size_t)r * ld + c;
+        *p = m2f_keep(key, (uint32_t)e, thresh) ? *p * scale : 0.f;
+    }
+}
+
+__global__ void m2f_rng_advance_kernel(uint32_t* rng) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t lo = rng[2] + 1u;
+        rng[2] = lo;
+        if (lo == 0u) rng[3] += 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n4, float lr_bc1, float beta1, float beta2,
+                                                       float eps, float wd, float inv_sqrt_bc2, const float* __restrict__ gs_ptr) {
+    const float gs = gs_ptr ? 1.0f / *gs_ptr : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gs + wd * pp[e];                  // coupled L2 (Adam, not AdamW)
+            mm[e] = beta1 * mm[e] + (1.f - beta1) * gr;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+            const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+            pp[e] -= lr_bc1 * (mm[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+}
+
+template <bool BWD>
+hipError_t ln_launch(LnBatch& lb, hipStream_t stream) {
+    if (lb.count <= 0 || lb.count > M2F_LN_MAX_PROBLEMS || lb.T <= 0) return hipErrorInvalidValue;
+    int blocks = 0, maxd = 0;
+    for (int i = 0; i < lb.count; ++i) {
+        LnProblem& p = lb.pr[i];
+        if (p.d < 1 || p.d > 256 * LN_MAXV_LIMIT) return hipErrorInvalidValue;
+        if ((p.drop_site || p.drop_site2) && !lb.rng) return hipErrorInvalidValue;
+        p.block_begin = blocks;
+        blocks += m2f_ln_row_blocks(lb.T);
+        if (p.d > maxd) maxd = p.d;
+    }
+    const size_t lds = BWD ? (size_t)LN_WAVES * 2 * ((maxd + 3) & ~3) * sizeof(float) : 0;
+    const int nv = m2f_cdiv(maxd, 256);
+#define M2F_LN_CASE(N)                                                                                      \
+    if (nv <= N) {                                                                                          \
+        if (BWD) hipLaunchKernelGGL(m2f_ln_bwd_kernel<N>, dim3(blocks), dim3(256), lds, stream, lb);        \
+        else hipLaunchKernelGGL(m2f_ln_fwd_kernel<N>, dim3(blocks), dim3(256), 0, stream, lb);              \
+        return hipGetLastError();                                                                           \
+    }
+    M2F_LN_CASE(1)
+    M2F_LN_CASE(2)
+    M2F_LN_CASE(3)
+    M2F_LN_CASE(4)
+    M2F_LN_CASE(8)
+#undef M2F_LN_CASE
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t m2f_launch_ln_fwd(LnBatch& lb, hipStream_t stream) { return ln_launch<false>(lb, stream); }
+hipError_t m2f_launch_ln_bwd(LnBatch& lb, hipStream_t stream) { return ln_launch<true>(lb, stream); }
+
+hipError_t m2f_launch_ln_param_reduce(const LnReduceBatch& rb, hipStream_t stream) {
+    if (rb.count <= 0) return hipSuccess;
+    if (rb.count > M2F_LNRED_MAX_ITEMS) return hipErrorInvalidValue;
+    int maxd = 0;
+    for (int i = 0; i < rb.count; ++i) if (rb.it[i].d > maxd) maxd = rb.it[i].d;
+    hipLaunchKernelGGL(m2f_ln_param_reduce_kernel, dim3(m2f_cdiv(maxd, 256), rb.count), dim3(256), 0, stream, rb);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_ce(const CeArgs& a, hipStream_t stream) {
+    if (a.C < 1 || a.C > 16 || a.T < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(m2f_ce_kernel, dim3(m2f_cdiv(a.T, 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_loss_finalize(const float* loss_terms, int T, int C, float* dlogits, float* loss_out,
+                                    int normalise, hipStream_t stream) {
+    hipLaunchKernelGGL(m2f_loss_finalize_kernel, dim3(1), dim3(256), 0, stream, loss_terms, T, C, dlogits, loss_out, normalise);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
+                                      uint32_t thresh, float scale, hipStream_t stream) {
+    const size_t n = (size_t)T * d;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(m2f_dropout_inplace_kernel, dim3(blocks), dim3(256), 0, stream, x, T, d, ld, site, rng, thresh, scale);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream) {
+    hipLaunchKernelGGL(m2f_rng_advance_kernel, dim3(1), dim3(64), 0, stream, rng);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
+                           hipStream_t stream) {
+    if (n & 3) return hipErrorInvalidValue;      // flat buffers are padded to 64 floats per tensor
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int64_t n4 = n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(m2f_adam_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, (float)(lr / bc1), beta1, beta2, eps,
+                       weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
+    return hipGetLastError();
+}

@@ -1,0 +1,289 @@
+"""``M2FNet`` / ``FusionAttentionModule``: host-side mirrors of the reference's ``src/model.py``.
+
+Same constructor arguments, ``forward`` signature, ``state_dict`` keys and default initialisation as
+/root/reference/src/model.py:5-145, but the modules here only HOLD parameters (as views into one flat
+fp32 buffer in HBM); every forward/backward FLOP runs in the gfx950 kernels behind ``runtime.Plan``.
+No ``nn.Transformer*`` / ``nn.MultiheadAttention`` / ``nn.Linear`` forward is ever called.
+"""
+from __future__ import annotations
+
+import copy
+import math
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import runtime
+from .layout import M2FConfig, param_specs
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameter holders (names chosen so the state_dict keys equal the reference's)
+# ------------------------------------------------------------------------------------------------------
+class _LinearParams(nn.Module):
+    """weight [out, in], bias [out]; default init of nn.Linear (kaiming_uniform(a=sqrt(5)) + fan-in bias)."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_features) if in_features > 0 else 0.0
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _NormParams(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _MHAParams(nn.Module):
+    """in_proj_weight [3E, E] (xavier-uniform), in_proj_bias = 0, out_proj.{weight, bias = 0}:
+    the parameter set and init order of nn.MultiheadAttention (out_proj is created before the
+    xavier init of in_proj_weight, so the RNG is consumed in the same order as the reference)."""
+
+    def __init__(self, embed_dim: int, num_heads: int):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = _LinearParams(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class _EncoderLayerParams(nn.Module):
+    def __init__(self, d: int, n_head: int, dim_ff: int):
+        super().__init__()
+        self.self_attn = _MHAParams(d, n_head)
+        self.linear1 = _LinearParams(d, dim_ff)
+        self.linear2 = _LinearParams(dim_ff, d)
+        self.norm1 = _NormParams(d)
+        self.norm2 = _NormParams(d)
+
+
+class _EncoderStack(nn.Module):
+    """nn.TransformerEncoder(encoder_layer, num_layers, norm): the layers are deep copies of ONE template
+    (identical initial weights), the final norm object is shared, not cloned (model.py:61-65)."""
+
+    def __init__(self, template: _EncoderLayerParams, d: int, n_head: int, dim_ff: int, num_layers: int,
+                 norm: _NormParams):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(template) for _ in range(num_layers)])
+        self.norm = norm
+
+
+class FusionAttentionModule(nn.Module):
+    """Mirror of reference src/model.py:5-20.  Inside ``M2FNet`` it is a parameter holder (the fusion stack
+    runs in the plan); called on its own it executes the same gfx950 kernels layer-wise (inference only)."""
+
+    def __init__(self, embedding_size: int, n_head: int, dropout: float):
+        super().__init__()
+        self.multihead_attention = _MHAParams(embedding_size, n_head)
+        self.linear = _LinearParams(2 * embedding_size, embedding_size)
+        self.relu = nn.ReLU()
+        self.embedding_size, self.n_head, self.dropout_p = embedding_size, n_head, dropout
+
+    def forward(self, text: torch.Tensor, audio: torch.Tensor, key_padding_mask: torch.Tensor) -> torch.Tensor:
+        from . import functional as F
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("standalone FusionAttentionModule.forward is inference-only; train it inside M2FNet "
+                               "(wrap the call in torch.no_grad())")
+        return F.fam_layer_forward(text, audio, key_padding_mask, self.multihead_attention.in_proj_weight,
+                                   self.multihead_attention.in_proj_bias, self.multihead_attention.out_proj.weight,
+                                   self.multihead_attention.out_proj.bias, self.linear.weight, self.linear.bias,
+                                   self.n_head)
+
+
+class _Anchor(torch.autograd.Function):
+    """Connects the plan's forward/backward to autograd through ONE dummy leaf: ``loss.backward()``
+    (reference src/train.py:230) reaches ``backward`` below, which runs the HIP backward launch list and
+    publishes the flat gradient buffer as the parameters' ``.grad`` views."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan):
+        eng = model._engine
+        if plan.cfg.dropout > 0.0 and plan.train:
+            runtime.check(runtime.lib().m2f_rng_advance(eng.rng.data_ptr(), runtime.stream_ptr()), "m2f_rng_advance")
+        logits = plan.forward()
+        ctx.model, ctx.plan, ctx.version = model, plan, plan.version
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        plan = ctx.plan
+        if plan.version != ctx.version:
+            raise RuntimeError("M2FNet: the activations of this forward were overwritten by a later forward of the "
+                               "same (B, L) shape; call backward() before the next forward()")
+        plan.dlogits.copy_(dlogits.reshape(plan.dlogits.shape))
+        plan.backward()
+        ctx.model._engine.publish_grads()
+        return None, None, None
+
+
+class _Engine:
+    """Device state of one M2FNet: flat parameter / gradient buffers, dropout RNG state, plan cache."""
+
+    def __init__(self, model: "M2FNet", device: torch.device):
+        runtime.require_gpu()
+        self.model, self.device, self.cfg = model, device, model.m2f_config
+        total = runtime.verify_layout(self.cfg)
+        specs, _ = param_specs(self.cfg)
+        named = dict(model.named_parameters(remove_duplicate=False))
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_grad: Optional[torch.Tensor] = None
+        self.items = []                       # (param, offset, numel, shape)
+        seen = set()
+        with torch.no_grad():
+            for sp in specs:
+                p = named[sp.name]
+                if sp.alias_of or id(p) in seen:
+                    continue
+                seen.add(id(p))
+                view = self.flat[sp.offset: sp.offset + sp.numel].view(sp.shape)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+                self.items.append((p, sp.offset, sp.numel, sp.shape))
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        to_i32 = lambda u: u - (1 << 32) if u >= (1 << 31) else u
+        self.rng = torch.tensor([to_i32(lo), to_i32(hi), 0, 0], dtype=torch.int32, device=device)
+        self.plans: Dict[Tuple, runtime.Plan] = {}
+        self.grad_views = None
+        self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.precision = runtime.PRECISIONS[model.precision]
+
+    def ensure_grad(self) -> torch.Tensor:
+        if self.flat_grad is None:
+            self.flat_grad = torch.zeros_like(self.flat)
+            self.grad_views = [self.flat_grad[o: o + n].view(s) for (_, o, n, s) in self.items]
+        return self.flat_grad
+
+    def plan(self, B: int, L: int, want_backward: bool, dropout_active: bool) -> runtime.Plan:
+        key = (B, L, want_backward, dropout_active, self.precision)
+        pl = self.plans.get(key)
+        if pl is None:
+            cfg = self.cfg
+            if not dropout_active and cfg.dropout != 0.0:
+                cfg = M2FConfig(**{**cfg.__dict__, "dropout": 0.0})
+            grads = self.ensure_grad() if want_backward else None
+            pl = runtime.Plan(cfg, B, L, self.precision, want_backward, self.flat, grads, self.rng)
+            self.plans[key] = pl
+        return pl
+
+    def publish_grads(self) -> None:
+        """Expose the flat gradient buffer as ``p.grad`` views.  Gradients are OVERWRITTEN each backward
+        (the reference zeroes them every step, src/train.py:227); a foreign ``.grad`` tensor is added to."""
+        for (p, _, _, _), v in zip(self.items, self.grad_views):
+            g = p.grad
+            if g is None:
+                p.grad = v
+            elif g is not v and g.data_ptr() != v.data_ptr():
+                g.add_(v)
+
+    def owns(self) -> bool:
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for (p, o, _, _) in self.items)
+
+
+class M2FNet(nn.Module):
+    """Drop-in for reference ``src/model.py:23-145``: ``M2FNet(config.model)``; ``forward(text, audio, mask)``
+    with text [B,L,d_t], audio [B,L,d_a] fp32 and mask bool [B,L] (True = pad) -> logits [B,L,output_size]."""
+
+    def __init__(self, config, precision: Optional[str] = None):
+        super().__init__()
+        self.config = config
+        c = M2FConfig.from_model_config(config)           # raises the reference's two ValueErrors
+        self.m2f_config = c
+        self.audio_enabled, self.text_enabled, self.fam_enabled = c.audio_enabled, c.text_enabled, c.fam_enabled
+        self.n_head_audio, self.n_head_text, self.n_head_fam = c.nhead_audio, c.nhead_text, c.nhead_fam
+        self.dropout = nn.Dropout(c.dropout)               # kept for attribute parity; never called
+        # GEMM operand precision: "fp32" (exact-fp32 MFMA, the 1e-3 parity mode) or "bf16" (bf16 MFMA, fp32 accumulate)
+        self.precision = precision or os.environ.get("M2F_PRECISION", "fp32")
+        if self.precision not in runtime.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(runtime.PRECISIONS)}")
+
+        # construction order == reference (model.py:59-100) so that a given torch seed yields the same weights
+        if c.audio_enabled:
+            tmpl = _EncoderLayerParams(c.d_audio, c.nhead_audio, c.dim_ff)
+            norm = _NormParams(c.d_audio)
+            self.audio_encoders = nn.ModuleList([
+                _EncoderStack(tmpl, c.d_audio, c.nhead_audio, c.dim_ff, c.nlayers_audio, norm)
+                for _ in range(c.ntrans_audio)])
+            self.audio_proj = _LinearParams(c.d_audio, c.d_fam)
+        if c.text_enabled:
+            tmpl = _EncoderLayerParams(c.d_text, c.nhead_text, c.dim_ff)
+            norm = _NormParams(c.d_text)
+            self.text_encoders = nn.ModuleList([
+                _EncoderStack(tmpl, c.d_text, c.nhead_text, c.dim_ff, c.nlayers_text, norm)
+                for _ in range(c.ntrans_text)])
+            self.text_proj = _LinearParams(c.d_text, c.d_fam)
+        if c.fam_enabled:
+            self.fusion_layers = nn.ModuleList([
+                FusionAttentionModule(embedding_size=c.d_fam, n_head=c.nhead_fam, dropout=c.dropout)
+                for _ in range(c.nlayers_fam)])
+        head = [_LinearParams(c.cls_in, c.cls_hidden)]
+        for _ in range(max(c.cls_layers - 2, 0)):
+            head.append(nn.ReLU())
+            head.append(_LinearParams(c.cls_hidden, c.cls_hidden))
+        head.append(nn.ReLU())
+        head.append(self.dropout)
+        head.append(_LinearParams(c.cls_hidden, c.cls_out))
+        self.output_layer = nn.Sequential(*head)
+        self._engine: Optional[_Engine] = None
+
+    # -- device plumbing -------------------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        self._engine = None                                # .to()/.cuda()/.cpu() re-home the parameters
+        return super()._apply(fn, *args, **kwargs)
+
+    def engine(self, device: Optional[torch.device] = None) -> _Engine:
+        if device is None:
+            device = next(self.parameters()).device
+        if device.type != "cuda":
+            raise runtime.HipError("M2FNet runs only on an MI355X (gfx950): move the model and the batch to 'cuda' "
+                                   "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
+        if self._engine is None or self._engine.device != device or not self._engine.owns():
+            self._engine = _Engine(self, device)
+        return self._engine
+
+    # -- reference surface -----------------------------------------------------------------------------
+    def forward(self, text, audio, mask):
+        eng = self.engine(mask.device)
+        B, L = mask.shape
+        want_bwd = torch.is_grad_enabled() and any(p.requires_grad for p, *_ in eng.items)
+        plan = eng.plan(B, L, want_bwd, self.training and self.m2f_config.dropout > 0.0)
+        plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask)
+        if want_bwd:
+            return _Anchor.apply(eng.anchor, self, plan)
+        if plan.train and plan.cfg.dropout > 0.0:
+            runtime.check(runtime.lib().m2f_rng_advance(eng.rng.data_ptr(), runtime.stream_ptr()), "m2f_rng_advance")
+        return plan.forward().clone()
+
+    # -- fused fast path (forward + criterion + backward as one launch list / hipGraph) ---------------
+    def train_step(self, text, audio, mask, emotion, label_smoothing: float = 0.1,
+                   class_weights: Optional[torch.Tensor] = None, normalise: bool = True,
+                   use_graph: bool = True) -> torch.Tensor:
+        """Body of reference src/train.py:227-230 in one call: returns the (device) loss scalar and leaves
+        the gradients in ``p.grad`` (views of the flat buffer)."""
+        eng = self.engine(mask.device)
+        B, L = mask.shape
+        plan = eng.plan(B, L, True, self.training and self.m2f_config.dropout > 0.0)
+        plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask, emotion)
+        if class_weights is not None:
+            plan.class_w[: class_weights.numel()].copy_(class_weights)
+        loss = plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+        eng.publish_grads()
+        return loss[0]
+
+    def flat_parameters(self) -> torch.Tensor:
+        return self.engine().flat
+
+    def flat_gradients(self) -> torch.Tensor:
+        return self.engine().ensure_grad()

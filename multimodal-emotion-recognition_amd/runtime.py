@@ -1,0 +1,246 @@
+"""ctypes binding of ``csrc/libm2fnet_hip.so`` (C ABI: ``include/m2fnet_hip.h``).
+
+PyTorch is used for plumbing only: device memory (tensors), the current HIP stream and, in ``dp.py``,
+``torch.distributed`` (RCCL).  All arithmetic of the hot path happens in the HIP kernels behind this
+binding.  There is NO fallback: if the shared library is missing or the device is not gfx950 the import /
+first use raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .layout import M2FConfig, param_specs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libm2fnet_hip.so")
+HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "include", "m2fnet_hip.h"))
+
+F32, BF16 = 0, 1
+PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+(BUF_TEXT, BUF_AUDIO, BUF_KEYPAD, BUF_LABELS, BUF_CLASSW, BUF_LOGITS, BUF_LOSS, BUF_DLOGITS,
+ BUF_FAM0_OUT) = range(9)
+
+c_void_p, c_int, c_float, c_int64, c_uint32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_int64, ctypes.c_uint32)
+
+
+class M2FConfigC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "audio_enabled", "text_enabled", "fam_enabled", "d_audio", "d_text", "d_fam",
+        "nhead_audio", "nhead_text", "nhead_fam", "nlayers_audio", "nlayers_text", "nlayers_fam",
+        "ntrans_audio", "ntrans_text", "cls_hidden", "cls_out", "cls_layers", "dim_ff")] + [
+        ("dropout", ctypes.c_float), ("ln_eps", ctypes.c_float)]
+
+
+def config_to_c(c: M2FConfig) -> M2FConfigC:
+    return M2FConfigC(int(c.audio_enabled), int(c.text_enabled), int(c.fam_enabled), c.d_audio, c.d_text, c.d_fam,
+                      c.nhead_audio, c.nhead_text, c.nhead_fam, c.nlayers_audio, c.nlayers_text, c.nlayers_fam,
+                      c.ntrans_audio, c.ntrans_text, c.cls_hidden, c.cls_out, c.cls_layers, c.dim_ff,
+                      float(c.dropout), float(c.ln_eps))
+
+
+class HipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/m2fnet_hip.h declares
+SIGNATURES = {
+    "m2f_last_error": (ctypes.c_char_p, []),
+    "m2f_device_check": (c_int, []),
+    "m2f_param_layout": (c_int, [ctypes.POINTER(M2FConfigC), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int,
+                                 ctypes.POINTER(c_int64)]),
+    "m2f_workspace_bytes": (c_int64, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int]),
+    "m2f_plan_create": (c_void_p, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_void_p]),
+    "m2f_plan_destroy": (None, [c_void_p]),
+    "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
+    "m2f_plan_num_launches": (c_int, [c_void_p, c_int]),
+    "m2f_forward": (c_int, [c_void_p, c_void_p]),
+    "m2f_loss": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),
+    "m2f_backward": (c_int, [c_void_p, c_void_p]),
+    "m2f_step": (c_int, [c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "m2f_rng_advance": (c_int, [c_void_p, c_void_p]),
+    "m2f_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                              c_float, c_int, c_void_p, c_void_p]),
+    "m2f_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                         c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float,
+                         c_void_p, c_int, c_int, c_int, c_int, c_uint32, c_float, c_void_p, c_int, c_void_p]),
+    "m2f_attention_fwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_uint32, c_float, c_void_p, c_void_p]),
+    "m2f_attention_bwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                  c_int, c_void_p, c_int, c_uint32, c_float, c_void_p, c_void_p]),
+    "m2f_attention_probs_elems": (c_int64, [c_int, c_int, c_int]),
+    "m2f_layernorm_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                  c_void_p]),
+    "m2f_layernorm_bwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "m2f_cross_entropy": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded shared library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback exists). "
+                f"Build it with `make -C {CSRC}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        raise HipError(f"{what}: {lib().m2f_last_error().decode()} (code {code})")
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise HipError("the M2FNet HIP path needs an MI355X (gfx950) GPU; there is no CPU fallback")
+    check(lib().m2f_device_check(), "m2f_device_check")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def c_param_layout(c: M2FConfig) -> Tuple[list, list, int]:
+    cc = config_to_c(c)
+    n_max = 4096
+    offs = (c_int64 * n_max)()
+    nums = (c_int64 * n_max)()
+    total = c_int64(0)
+    n = lib().m2f_param_layout(ctypes.byref(cc), offs, nums, n_max, ctypes.byref(total))
+    if n < 0:
+        raise HipError(lib().m2f_last_error().decode())
+    return list(offs[:n]), list(nums[:n]), int(total.value)
+
+
+def verify_layout(c: M2FConfig) -> int:
+    """Cross-check layout.py against the C side; returns the flat length in elements."""
+    specs, total = param_specs(c)
+    uniq = [s for s in specs if not s.alias_of]
+    offs, nums, ctotal = c_param_layout(c)
+    if ctotal != total or offs != [s.offset for s in uniq] or nums != [s.numel for s in uniq]:
+        raise HipError("flat parameter layout mismatch between layout.py and csrc/plan.hip")
+    return total
+
+
+class Plan:
+    """One bound launch list (config, B, L, precision, train/eval) + its workspace."""
+
+    def __init__(self, cfg: M2FConfig, B: int, L: int, precision: int, train: bool, params: torch.Tensor,
+                 grads: Optional[torch.Tensor], rng_state: Optional[torch.Tensor]):
+        require_gpu()
+        self.cfg, self.B, self.L, self.T = cfg, B, L, B * L
+        self.precision, self.train = precision, train
+        self._cc = config_to_c(cfg)
+        nbytes = lib().m2f_workspace_bytes(ctypes.byref(self._cc), B, L, int(train))
+        if nbytes < 0:
+            raise HipError(lib().m2f_last_error().decode())
+        self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=params.device)
+        base = self.workspace.data_ptr()
+        self._ws_off = (-base) % 256
+        self._keep = (params, grads, rng_state)
+        self.handle = lib().m2f_plan_create(ctypes.byref(self._cc), B, L, precision, int(train), params.data_ptr(),
+                                            ptr(grads), base + self._ws_off, nbytes, ptr(rng_state))
+        if not self.handle:
+            raise HipError("m2f_plan_create: " + lib().m2f_last_error().decode())
+        C = cfg.cls_out
+        self.text_in = self._view(BUF_TEXT, (self.T, max(cfg.d_text, 1)), torch.float32)
+        self.audio_in = self._view(BUF_AUDIO, (self.T, max(cfg.d_audio, 1)), torch.float32)
+        self.keypad_in = self._view(BUF_KEYPAD, (self.T,), torch.uint8)
+        self.labels_in = self._view(BUF_LABELS, (self.T,), torch.int64)
+        self.class_w = self._view(BUF_CLASSW, (16,), torch.float32)
+        self.logits = self._view(BUF_LOGITS, (B, L, C), torch.float32)
+        self.loss = self._view(BUF_LOSS, (4,), torch.float32)
+        self.dlogits = self._view(BUF_DLOGITS, (B, L, C), torch.float32)
+        self.fam0_out = self._view(BUF_FAM0_OUT, (B, L, cfg.d_fam), torch.float32) if cfg.fam_enabled else None
+        self.version = 0          # bumped by every forward; backward checks it still owns the activations
+
+    def _view(self, which: int, shape, dtype) -> torch.Tensor:
+        p = lib().m2f_plan_buffer(self.handle, which)
+        if not p:
+            raise HipError(f"plan buffer {which} missing")
+        off = p - self.workspace.data_ptr()
+        n = 1
+        for s in shape:
+            n *= s
+        esize = torch.empty(0, dtype=dtype).element_size()
+        return self.workspace[off: off + n * esize].view(dtype).view(*shape)
+
+    def num_launches(self) -> Dict[str, int]:
+        return {k: lib().m2f_plan_num_launches(self.handle, i) for i, k in enumerate(("forward", "loss", "backward"))}
+
+    def set_inputs(self, text: Optional[torch.Tensor], audio: Optional[torch.Tensor], key_pad: torch.Tensor,
+                   labels: Optional[torch.Tensor] = None) -> None:
+        """Device-to-device copies of one batch into the plan's staging buffers (async on the stream)."""
+        if text is not None and self.cfg.text_enabled:
+            self.text_in.copy_(text.reshape(self.T, -1), non_blocking=True)
+        if audio is not None and self.cfg.audio_enabled:
+            self.audio_in.copy_(audio.reshape(self.T, -1), non_blocking=True)
+        self.keypad_in.copy_(key_pad.reshape(self.T), non_blocking=True)
+        if labels is not None:
+            self.labels_in.copy_(labels.reshape(self.T), non_blocking=True)
+
+    def forward(self) -> torch.Tensor:
+        self.version += 1
+        check(lib().m2f_forward(self.handle, stream_ptr()), "m2f_forward")
+        return self.logits
+
+    def loss_fwd(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True):
+        check(lib().m2f_loss(self.handle, label_smoothing, int(use_class_weights), int(normalise), stream_ptr()),
+              "m2f_loss")
+        return self.loss
+
+    def backward(self) -> None:
+        check(lib().m2f_backward(self.handle, stream_ptr()), "m2f_backward")
+
+    def step(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True,
+             use_graph: bool = True) -> torch.Tensor:
+        self.version += 1
+        check(lib().m2f_step(self.handle, label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
+                             stream_ptr()), "m2f_step")
+        return self.loss
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _lib is not None:
+            _lib.m2f_plan_destroy(h)
+            self.handle = None
+
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+              lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+              grad_scale: Optional[torch.Tensor] = None) -> None:
+    check(lib().m2f_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                              params.numel(), lr, betas[0], betas[1], eps, weight_decay, step, ptr(grad_scale),
+                              stream_ptr()), "m2f_adam_step")

@@ -1,0 +1,227 @@
+"""GPU parity tests of each HIP kernel (called through the C ABI) against plain fp32 tensor math.
+
+Tolerances: fp32 mode (exact-fp32 MFMA) 2e-5 relative to the output scale; bf16 mode (operands rounded
+to bf16, fp32 accumulate) 1.5e-2 relative to the output scale.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mer_amd  # noqa: E402
+from mer_amd import functional as F  # noqa: E402
+from mer_amd import runtime  # noqa: E402
+from oracle import m2fnet_oracle as O  # noqa: E402
+
+DEV = "cuda"
+TOL = {runtime.F32: 2e-5, runtime.BF16: 1.5e-2}
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _close(a, b, tol, what=""):
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale + 1e-7, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+@pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", [(70, 50, 45), (512, 768, 768), (129, 300, 300), (64, 7, 768), (33, 2048, 96)])
+def test_gemm_layouts(prec, tile, shape):
+    M, N, K = shape
+    a = _rand(M, K, seed=1)
+    b_nk = _rand(N, K, seed=2)
+    ref = a.double() @ b_nk.double().t()
+    _close(F.gemm(a, b_nk, F.NT, prec, tile=tile).double(), ref, TOL[prec], "NT")
+    b_kn = b_nk.t().contiguous()
+    _close(F.gemm(a, b_kn, F.NN, prec, tile=tile).double(), ref, TOL[prec], "NN")
+    a_km = a.t().contiguous()
+    c, bg = F.gemm(a_km, b_kn, F.TN, prec, tile=tile, bias_grad=True)
+    _close(c.double(), ref, TOL[prec], "TN")
+    _close(bg.double(), a_km.double().sum(dim=0), 1e-5, "bias_grad")
+
+
+@pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
+def test_gemm_epilogue_and_segments(prec):
+    M, N, K0, K1 = 96, 80, 64, 40
+    a0, a1 = _rand(M, K0, seed=3), _rand(M, K1, seed=4)
+    w = _rand(N, K0 + K1, seed=5)
+    bias, res, gate = _rand(N, seed=6), _rand(M, N, seed=7), _rand(M, N, seed=8)
+    pre = torch.relu(torch.cat((a0, a1), dim=1)).double() @ w.double().t() + bias.double()
+    ref = (torch.relu(pre) + res.double()) * (gate > 0).double() * 1.5
+    out = F.gemm(a0, w[:, :K0], F.NT, prec, a1=a1, b1=w[:, K0:], bias=bias, res=res, gate=gate, gate_scale=1.5,
+                 relu_a=True, relu_out=True)
+    _close(out.double(), ref, TOL[prec], "fused epilogue")
+    base = _rand(M, N, seed=9)
+    acc = base.clone()
+    F.gemm(a0, w[:, :K0], F.NT, prec, out=acc, accumulate=True)
+    _close(acc.double(), base.double() + a0.double() @ w[:, :K0].double().t(), TOL[prec], "accumulate")
+    # strided C (column block of a wider matrix) + relu on the B operand of a wgrad
+    big = torch.zeros(N, 2 * K0, device=DEV)
+    dy = _rand(M, N, seed=10)
+    F.gemm(dy, a0, F.TN, prec, out=big[:, K0:], relu_b=True)
+    _close(big[:, K0:].double(), dy.double().t() @ torch.relu(a0).double(), TOL[prec], "wgrad strided")
+    assert big[:, :K0].abs().max().item() == 0.0
+
+
+def test_gemm_dropout_epilogue_statistics_and_replay():
+    M, N, K, p = 256, 512, 64, 0.4
+    a, b = _rand(M, K, seed=11), _rand(N, K, seed=12)
+    rng = torch.tensor([123, 456, 7, 0], dtype=torch.int32, device=DEV)
+    plain = F.gemm(a, b)
+    d1 = F.gemm(a, b, drop_site=5, drop_p=p, rng=rng)
+    d2 = F.gemm(a, b, drop_site=5, drop_p=p, rng=rng)
+    assert torch.equal(d1, d2), "mask must be a pure function of (state, site, index)"
+    kept = d1 != 0
+    rate = kept.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    _close(d1[kept].double(), (plain[kept] / (1 - p)).double(), 1e-6, "kept values scaled by 1/(1-p)")
+    d3 = F.gemm(a, b, drop_site=6, drop_p=p, rng=rng)
+    assert (d3 != 0).ne(kept).float().mean().item() > 0.3, "different sites must give different masks"
+    rng2 = rng.clone()
+    rng2[2] += 1
+    d4 = F.gemm(a, b, drop_site=5, drop_p=p, rng=rng2)
+    assert (d4 != 0).ne(kept).float().mean().item() > 0.3, "different steps must give different masks"
+    # rows / columns are not correlated
+    assert abs(kept.float().mean(dim=0).std().item()) < 0.06 and abs(kept.float().mean(dim=1).std().item()) < 0.06
+
+
+def _attn_case(B, L, H, hd, seed, lengths=None):
+    E = H * hd
+    q, k, v = _rand(B * L, E, seed=seed), _rand(B * L, E, seed=seed + 1), _rand(B * L, E, seed=seed + 2)
+    key_pad = torch.zeros(B, L, dtype=torch.bool)
+    if lengths:
+        for b, n in enumerate(lengths):
+            key_pad[b, n:] = True
+    return q, k, v, key_pad.to(DEV)
+
+
+@pytest.mark.parametrize("B,L,H,hd,lengths", [
+    (4, 16, 8, 96, [16, 9, 1, 12]), (3, 33, 4, 15, [33, 17, 2]), (2, 9, 2, 24, None), (2, 64, 2, 128, [64, 40]),
+    (5, 7, 3, 75, [7, 7, 3, 1, 5])])
+def test_attention_forward_backward(B, L, H, hd, lengths):
+    q, k, v, key_pad = _attn_case(B, L, H, hd, 20, lengths)
+    out, probs = F.attention_fwd(q, k, v, key_pad, B, L, H)
+    E = H * hd
+    qr, kr, vr = (t.detach().clone().view(B, L, E).requires_grad_(True) for t in (q, k, v))
+    ref, p_ref = O.attention(qr, kr, vr, key_pad, H, return_probs=True)
+    _close(out.view(B, L, E), ref.detach(), 2e-5, "attention out")
+    Lp = probs.shape[-1]
+    _close(probs.view(B, H, Lp, Lp)[:, :, :L, :L].transpose(-1, -2), p_ref.detach(), 2e-5, "probs")
+    dout = _rand(B * L, E, seed=30)
+    ref.backward(dout.view(B, L, E))
+    dq, dk, dv = F.attention_bwd(q, k, v, key_pad, out, probs, dout, B, L, H)
+    _close(dq.view(B, L, E), qr.grad, 3e-5, "dq")
+    _close(dk.view(B, L, E), kr.grad, 3e-5, "dk")
+    _close(dv.view(B, L, E), vr.grad, 3e-5, "dv")
+
+
+def test_attention_cross_strided_operands():
+    """FusionAttentionModule form: q and v live in one [T, 2E] buffer, k in another (src/model.py:14)."""
+    B, L, H, hd = 3, 12, 4, 32
+    E = H * hd
+    qv = _rand(B * L, 2 * E, seed=40)
+    k = _rand(B * L, E, seed=41)
+    key_pad = torch.zeros(B, L, dtype=torch.bool, device=DEV)
+    key_pad[1, 5:] = True
+    out, probs = F.attention_fwd(qv[:, :E], k, qv[:, E:], key_pad, B, L, H)
+    ref = O.attention(qv[:, :E].reshape(B, L, E), k.view(B, L, E), qv[:, E:].reshape(B, L, E), key_pad, H)
+    _close(out.view(B, L, E), ref, 2e-5, "cross attention")
+
+
+def test_attention_dropout_backward_matches_autograd_with_same_mask():
+    B, L, H, hd, p = 2, 16, 2, 32, 0.4
+    E = H * hd
+    q, k, _, key_pad = _attn_case(B, L, H, hd, 50, [16, 11])
+    # V = [I_L | 0] per head exposes the dropped probabilities in the output
+    v = torch.zeros(B, L, H, hd, device=DEV)
+    for j in range(L):
+        v[:, j, :, j] = 1.0
+    v = v.view(B * L, E)
+    rng = torch.tensor([9, 8, 3, 0], dtype=torch.int32, device=DEV)
+    out, probs = F.attention_fwd(q, k, v, key_pad, B, L, H, drop_site=3, drop_p=p, rng=rng)
+    Lp = probs.shape[-1]
+    P = probs.view(B, H, Lp, Lp)[:, :, :L, :L].transpose(-1, -2)             # [B,H,i,j] pre-dropout
+    Pd = out.view(B, L, H, hd)[..., :L].permute(0, 2, 1, 3)                   # dropped probabilities
+    mask = (Pd != 0)
+    valid = P > 1e-12
+    rate = mask[valid].float().mean().item()
+    assert abs(rate - (1 - p)) < 0.08, rate
+    _close(Pd[mask], (P / (1 - p))[mask], 1e-5, "dropped probs scaled")
+    # autograd reference with the extracted mask and a random V
+    v2 = _rand(B * L, E, seed=55)
+    out2, probs2 = F.attention_fwd(q, k, v2, key_pad, B, L, H, drop_site=3, drop_p=p, rng=rng)
+    qr, kr, vr = (t.detach().clone().view(B, L, H, hd).permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v2))
+    s = (qr @ kr.transpose(-1, -2)) / math.sqrt(hd)
+    s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
+    pr = torch.softmax(s, dim=-1) * mask.float() / (1 - p)
+    o_ref = (pr @ vr).permute(0, 2, 1, 3).reshape(B * L, E)
+    _close(out2, o_ref.detach(), 2e-5, "dropout forward")
+    dout = _rand(B * L, E, seed=56)
+    o_ref.backward(dout)
+    dq, dk, dv = F.attention_bwd(q, k, v2, key_pad, out2, probs2, dout, B, L, H, drop_site=3, drop_p=p, rng=rng)
+    back = lambda g: g.permute(0, 2, 1, 3).reshape(B * L, E)
+    _close(dq, back(qr.grad), 3e-5, "dq dropout")
+    _close(dk, back(kr.grad), 3e-5, "dk dropout")
+    _close(dv, back(vr.grad), 3e-5, "dv dropout")
+
+
+@pytest.mark.parametrize("T,d", [(50, 768), (512, 300), (33, 50), (17, 2048), (64, 1024)])
+def test_layernorm_forward_backward(T, d):
+    x, g, b, res = _rand(T, d, seed=60, scale=3.0), 1 + 0.1 * _rand(d, seed=61), 0.1 * _rand(d, seed=62), _rand(T, d, seed=63)
+    out, stats = F.layernorm_fwd(x, g, b, res)
+    xr, gr, br = (t.detach().clone().requires_grad_(True) for t in (x, g, b))
+    ref = res + O.layer_norm(xr, gr, br)
+    _close(out, ref.detach(), 1e-5, "ln fwd")
+    dy, extra = _rand(T, d, seed=64), _rand(T, d, seed=65)
+    ref.backward(dy)
+    dx, dg, db = F.layernorm_bwd(x, g, stats, dy, extra)
+    _close(dx, xr.grad + extra, 2e-5, "ln dx")
+    _close(dg, gr.grad, 2e-5, "ln dgamma")
+    _close(db, br.grad, 2e-5, "ln dbeta")
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_cross_entropy_matches_torch(weighted):
+    T, C = 300, 7
+    logits = _rand(T, C, seed=70, scale=2.0)
+    g = torch.Generator().manual_seed(71)
+    labels = torch.randint(0, C, (T,), generator=g)
+    labels[torch.rand(T, generator=g) < 0.3] = -1
+    labels = labels.to(DEV)
+    w = torch.tensor([0.3, 1.2, 2.1, 1.3, 1.2, 5.3, 5.2], device=DEV) if weighted else None
+    lr = logits.detach().clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(weight=w, ignore_index=-1, label_smoothing=0.1)(lr, labels)
+    ref.backward()
+    out, dl = F.cross_entropy(logits, labels, w, 0.1, True)
+    assert abs(out[0].item() - ref.item()) < 2e-6
+    _close(dl, lr.grad, 1e-5, "dlogits")
+    out2, dl2 = F.cross_entropy(logits, labels, w, 0.1, False)
+    _close(dl2 / out2[1], lr.grad, 1e-5, "unnormalised dlogits / den")
+
+
+def test_adam_matches_torch():
+    n = 4096 + 64
+    p0, g = _rand(n, seed=80), _rand(n, seed=81)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 5):
+        gg = g * step
+        ref_p.grad = gg.clone()
+        opt.step()
+        runtime.adam_step(p, gg, m, v, step, 1e-3, (0.9, 0.999), 1e-8, 0.01)
+    _close(p, ref_p.detach(), 1e-6, "adam params")
+    # device-side gradient scale (data-parallel global denominator)
+    p2, m2, v2 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    den = torch.tensor([4.0], device=DEV)
+    runtime.adam_step(p2, g * 4.0, m2, v2, 1, 1e-3, (0.9, 0.999), 1e-8, 0.01, grad_scale=den)
+    p3, m3, v3 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    runtime.adam_step(p3, g, m3, v3, 1, 1e-3, (0.9, 0.999), 1e-8, 0.01)
+    _close(p2, p3, 1e-6, "grad_scale")

@@ -1,0 +1,72 @@
+"""Dialogue-level dataset with the reference's surface (``src/dataset.py``): ``Dataset(mode)``, ``__getitem__``
+-> {"text": [n, d_t], "audio": [n, d_a], "emotion": list of [1] tensors}, ``collate_fn`` -> {"text": [B, L, d_t],
+"audio": [B, L, d_a], "padding_mask": bool [B, L], "emotion": int64 [B, L] (-1 on pads)}.
+
+Unlike the reference (three full-DataFrame scans per utterance, src/dataset.py:35,43-45) the dialogue -> row
+index is built ONCE at construction, so ``__getitem__`` is two tensor gathers."""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from utils import get_config, get_text
+
+EMOTIONS = {"neutral": 0, "joy": 1, "sadness": 2, "anger": 3, "surprise": 4, "fear": 5, "disgust": 6}
+
+
+def build_dialogue_index(dialogue_ids, utterance_ids):
+    """Rows of each dialogue in Utterance_ID order; dialogues in order of first appearance."""
+    dialogue_ids = np.asarray(dialogue_ids)
+    utterance_ids = np.asarray(utterance_ids)
+    order = {}
+    for row, d in enumerate(dialogue_ids.tolist()):
+        order.setdefault(d, []).append(row)
+    index = []
+    for d, rows in order.items():
+        rows = np.asarray(rows)
+        index.append(rows[np.argsort(utterance_ids[rows], kind="stable")])
+    return list(order.keys()), index
+
+
+class Dataset(torch.utils.data.Dataset):
+    def __init__(self, mode="train", text_embeddings=None, audio_embeddings=None, table=None):
+        super().__init__()
+        self.mode = mode
+        if text_embeddings is None or audio_embeddings is None:
+            config = get_config()
+            with open(os.path.join(os.path.abspath(config.embeddings.text), f"{mode}.pkl"), "rb") as f:
+                text_embeddings = pickle.load(f)
+            with open(os.path.join(os.path.abspath(config.embeddings.audio), f"{mode}.pkl"), "rb") as f:
+                audio_embeddings = pickle.load(f)
+        self.text_embeddings, self.audio_embeddings = text_embeddings, audio_embeddings
+        self.text = get_text(mode) if table is None else table
+        self.text["Emotion"] = self.text["Emotion"].map(lambda e: EMOTIONS.get(e, e))
+        self.dialogue_ids, self.rows = build_dialogue_index(self.text["Dialogue_ID"].to_numpy(),
+                                                            self.text["Utterance_ID"].to_numpy())
+        self._labels = torch.as_tensor(self.text["Emotion"].to_numpy().astype(np.int64))
+        print(f"Loaded {len(self.dialogue_ids)} dialogues for {self.mode}ing")
+
+    def __len__(self):
+        return len(self.dialogue_ids)
+
+    def __getitem__(self, idx):
+        rows = torch.as_tensor(self.rows[idx])
+        return {"text": self.text_embeddings[rows], "audio": self.audio_embeddings[rows],
+                "emotion": [e.reshape(1) for e in self._labels[rows]]}
+
+    def get_labels(self):
+        return self.text["Emotion"].to_numpy()
+
+
+def collate_fn(batch):
+    B = len(batch)
+    L = max(d["text"].shape[0] for d in batch)
+    text = batch[0]["text"].new_zeros(B, L, batch[0]["text"].shape[1])
+    audio = batch[0]["audio"].new_zeros(B, L, batch[0]["audio"].shape[1])
+    emotion = torch.full((B, L), -1, dtype=torch.int64)          # -1 = ignored by the criterion
+    for i, d in enumerate(batch):
+        n = d["text"].shape[0]
+        text[i, :n], audio[i, :n] = d["text"], d["audio"]
+        emotion[i, :n] = torch.cat([torch.as_tensor(e).reshape(1) for e in d["emotion"]]).to(torch.int64)
+    return {"text": text, "audio": audio, "padding_mask": emotion == -1, "emotion": emotion}

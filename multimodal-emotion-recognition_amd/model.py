@@ -157,6 +157,7 @@ class _Engine:
         self.plans: Dict[Tuple, runtime.Plan] = {}
         self.grad_views = None
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.stream = torch.cuda.Stream(device=device)    # hipGraph capture is illegal on the default stream
         self.precision = runtime.PRECISIONS[model.precision]
 
     def ensure_grad(self) -> torch.Tensor:
@@ -172,8 +173,10 @@ class _Engine:
             cfg = self.cfg
             if not dropout_active and cfg.dropout != 0.0:
                 cfg = M2FConfig(**{**cfg.__dict__, "dropout": 0.0})
-            grads = self.ensure_grad() if want_backward else None
-            pl = runtime.Plan(cfg, B, L, self.precision, want_backward, self.flat, grads, self.rng)
+            # the C side couples "keeps a backward list" and "dropout active" in its train flag
+            train = want_backward or dropout_active
+            grads = self.ensure_grad() if train else None
+            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, grads, self.rng)
             self.plans[key] = pl
         return pl
 
@@ -275,10 +278,21 @@ class M2FNet(nn.Module):
         eng = self.engine(mask.device)
         B, L = mask.shape
         plan = eng.plan(B, L, True, self.training and self.m2f_config.dropout > 0.0)
-        plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask, emotion)
-        if class_weights is not None:
-            plan.class_w[: class_weights.numel()].copy_(class_weights)
-        loss = plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+
+        def body():
+            plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask, emotion)
+            if class_weights is not None:
+                plan.class_w[: class_weights.numel()].copy_(class_weights)
+            return plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+
+        if use_graph:                                    # capture / replay on the engine's own stream
+            cur = torch.cuda.current_stream(eng.device)
+            eng.stream.wait_stream(cur)
+            with torch.cuda.stream(eng.stream):
+                loss = body()
+            cur.wait_stream(eng.stream)
+        else:
+            loss = body()
         eng.publish_grads()
         return loss[0]
 

@@ -227,34 +227,40 @@ def test_dropout_train_mode_statistics():
     assert (acc / n - c).abs().mean().item() < 0.25
 
 
-def test_dropout_backward_consistent_with_forward_mask():
-    """Directional finite difference through the whole train-mode model with a FROZEN mask (rng step fixed)."""
-    cfg = synth._cfg(32, 32, 32, 2, 2, 2, 1, 1, 1, dropout=0.3)
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_dropout_backward_consistent_with_forward_mask(p_drop):
+    """Directional finite difference through the whole train-mode model with a FROZEN mask (rng step fixed);
+    p = 0 calibrates what the finite difference itself can resolve (ReLU kinks, fp32 loss)."""
+    cfg = synth._cfg(32, 32, 32, 2, 2, 2, 1, 1, 2, dropout=p_drop)
     text, audio, key_pad, emotion = (x.cuda() for x in synth.make_inputs(cfg, 4, 6, [6, 3, 5, 2], "randn"))
     m = _model(cfg, train=True)
     eng = m.engine(torch.device("cuda"))
-    plan = eng.plan(4, 6, True, True)
+    plan = eng.plan(4, 6, True, p_drop > 0)
     plan.set_inputs(text, audio, key_pad, emotion)
 
     def loss_at():
         plan.forward()
         return plan.loss_fwd(0.1, False, True)[0].double().item()
 
-    base = loss_at()
+    loss_at()
     plan.backward()
     flat, grad = eng.flat, eng.flat_grad.clone()
-    gen = torch.Generator().manual_seed(1)
-    direction = torch.randn(flat.numel(), generator=gen).cuda() * (flat != 0)
-    eps = 1e-3
     orig = flat.clone()
-    flat.add_(direction, alpha=eps)
-    lp = loss_at()
-    flat.copy_(orig).add_(direction, alpha=-eps)
-    lm = loss_at()
-    flat.copy_(orig)
-    fd = (lp - lm) / (2 * eps)
-    an = float((grad.double() * direction.double()).sum())
-    assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-3), (fd, an, base)
+    worst = 0.0
+    for seed in range(4):
+        gen = torch.Generator().manual_seed(seed)
+        direction = torch.randn(flat.numel(), generator=gen).cuda() * (flat != 0)
+        direction /= direction.norm()
+        eps = 2e-2                                       # |perturbation| = 0.02 in parameter space
+        flat.copy_(orig).add_(direction, alpha=eps)
+        lp = loss_at()
+        flat.copy_(orig).add_(direction, alpha=-eps)
+        lm = loss_at()
+        flat.copy_(orig)
+        fd = (lp - lm) / (2 * eps)
+        an = float((grad.double() * direction.double()).sum())
+        worst = max(worst, abs(fd - an) / max(abs(an), 1e-2))
+    assert worst < 3e-2, worst
 
 
 def test_state_dict_and_checkpoint_format(tmp_path):

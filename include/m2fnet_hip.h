@@ -47,7 +47,7 @@ enum {
     M2F_BUF_LABELS = 3,     /* int64 [B*L]           input  (batch["emotion"], -1 = ignore, :224)       */
     M2F_BUF_CLASSW = 4,     /* float [16]            input  optional class weights (src/train.py:45-48) */
     M2F_BUF_LOGITS = 5,     /* float [B*L, cls_out]  output (M2FNet.forward, src/model.py:145)          */
-    M2F_BUF_LOSS = 6,       /* float [4]: loss, denominator, numerator, -                                */
+    M2F_BUF_LOSS = 6,       /* float [4]: loss, denominator, numerator, - ; for train plans this IS grads[total..] */
     M2F_BUF_DLOGITS = 7,    /* float [B*L, cls_out]  d loss / d logits (written by m2f_loss, or by host) */
     M2F_BUF_FAM0_OUT = 8,   /* float [B*L, d_fam]    first fusion layer output (kernel-level parity)     */
     M2F_BUF_COUNT = 9
@@ -66,7 +66,10 @@ int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train);
 
 /* A plan = the launch list of one M2FNet step for fixed (cfg, B, L, precision, train/eval) bound to the
  * caller's flat parameter buffer, flat gradient buffer (may be NULL for eval plans), workspace and
- * dropout RNG state (4 x uint32 in device memory: seed_lo, seed_hi, step_lo, step_hi). */
+ * dropout RNG state (4 x uint32 in device memory: seed_lo, seed_hi, step_lo, step_hi).
+ * The gradient buffer must hold total + 64 floats (total from m2f_param_layout): the 64-float tail receives
+ * (loss, denominator, numerator) so that a data-parallel all-reduce of the whole buffer also sums the
+ * valid-utterance denominators. */
 m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, int train,
                           float* params, float* grads, void* workspace, int64_t workspace_bytes,
                           uint32_t* rng_state);
@@ -87,6 +90,13 @@ int m2f_backward(m2f_plan* plan, m2f_stream_t stream);
  * advanced on the device; use_graph=1 captures the launch list into a hipGraph once and replays it. */
 int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, int use_graph,
              m2f_stream_t stream);
+
+/* Measurement aid: one EAGER m2f_step with a hipEvent pair recorded on `stream` around every launch.  Fills, per
+ * launch, kinds[] (0/1/2 = grouped GEMM forward/dgrad/wgrad form, 3/4 attention fwd/bwd, 5/6 LayerNorm fwd/bwd,
+ * 7 dropout-mask, 8 criterion, 9 LayerNorm-parameter reduce), ms[] (device time) and flops[] (algorithmic FLOPs of
+ * the launch, 0 for row-wise kernels).  Synchronises the stream.  Returns the number of launches, or <0. */
+int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream,
+                   int max_entries, int* kinds, float* ms, double* flops);
 
 /* Advances the dropout RNG state by one step on the device (what nn.Dropout's generator advance is to the
  * reference; m2f_step does it itself). */

@@ -539,7 +539,12 @@ struct Builder {
         float* dlogits = ar.f((size_t)T * C);
         P.bufs[M2F_BUF_DLOGITS] = dlogits;
         P.loss_terms = ar.f((size_t)T * 2);
-        P.bufs[M2F_BUF_LOSS] = ar.f(4);
+        // train plans keep (loss, den, num) in the TAIL of the flat gradient buffer, so the data-parallel all-reduce
+        // carries the denominators along with the gradients and nothing has to be copied
+        {
+            float* ws_loss = ar.f(4);
+            P.bufs[M2F_BUF_LOSS] = (P.train && P.grads) ? P.grads + P.pm.total : ws_loss;
+        }
         if (!P.train) return;
 
         // ------------------------------ backward -----------------------------------------------------
@@ -767,9 +772,42 @@ int build_plan(m2f_plan& P, char* ws_base) {
     return 0;
 }
 
+// Optional per-launch timing (m2f_step_timed): hipEvents recorded on the launch stream around every launch.
+struct Profiler {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;
+    std::vector<double> flops;
+    hipStream_t s = nullptr;
+    void begin(int k, double f) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        ev.push_back(a); ev.push_back(b); kind.push_back(k); flops.push_back(f);
+        (void)hipEventRecord(a, s);
+    }
+    void end() { (void)hipEventRecord(ev.back(), s); }
+};
+thread_local Profiler* g_prof = nullptr;
+
+double gemm_flops(const GemmBatch& gb) {
+    double f = 0;
+    for (int i = 0; i < gb.count; ++i)
+        f += 2.0 * gb.pr[i].M * gb.pr[i].N * ((double)gb.pr[i].a.k[0] + gb.pr[i].a.k[1]);
+    return f;
+}
+double attn_flops(const AttnBatch& ab, bool bwd) {
+    double f = 0;
+    for (int i = 0; i < ab.count; ++i) f += (bwd ? 10.0 : 4.0) * ab.B * ab.pr[i].H * (double)ab.L * ab.L * ab.pr[i].hd;
+    return f;
+}
+
 int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s) {
     for (Launch& l : ls) {
         hipError_t e = hipSuccess;
+        if (g_prof) {
+            int k = l.kind == OP_GEMM ? l.layout : (l.kind + 2);     // 0..2 gemm NT/NN/TN, 3 attn fwd, 4 attn bwd, 5 ln fwd, 6 ln bwd, 7 dropout
+            double f = l.kind == OP_GEMM ? gemm_flops(l.gb) : (l.kind == OP_ATTN_FWD ? attn_flops(l.ab, false) : (l.kind == OP_ATTN_BWD ? attn_flops(l.ab, true) : 0.0));
+            g_prof->begin(k, f);
+        }
         switch (l.kind) {
             case OP_GEMM: e = m2f_launch_gemm(l.gb, P.prec, l.layout, 0, s); break;
             case OP_ATTN_FWD: e = m2f_launch_attn_fwd(l.ab, s); break;
@@ -778,6 +816,7 @@ int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s) {
             case OP_LN_BWD: e = m2f_launch_ln_bwd(l.lb, s); break;
             case OP_DROPOUT: e = m2f_launch_dropout_inplace(l.dptr, l.dT, l.dd, l.dld, l.dsite, P.rng, P.drop_thresh, P.drop_scale, s); break;
         }
+        if (g_prof) g_prof->end();
         if (e != hipSuccess) return hipfail(e, "kernel launch");
     }
     return 0;
@@ -792,15 +831,21 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
     a.label_smoothing = ls;
     a.loss_terms = P.loss_terms;
     a.dlogits = static_cast<float*>(P.bufs[M2F_BUF_DLOGITS]);
+    if (g_prof) g_prof->begin(8, 0.0);
     M2F_HIP(m2f_launch_ce(a, s));
     M2F_HIP(m2f_launch_loss_finalize(P.loss_terms, P.T, P.cfg.cls_out, a.dlogits, static_cast<float*>(P.bufs[M2F_BUF_LOSS]), normalise, s));
+    if (g_prof) g_prof->end();
     return 0;
 }
 
 int do_backward(m2f_plan& P, hipStream_t s) {
     if (!P.train || !P.grads) return fail("m2f_backward: plan was created without train=1 / gradient buffer");
     if (int r = run_launches(P, P.bwd, s)) return r;
-    for (const LnReduceBatch& rb : P.lnred) M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
+    for (const LnReduceBatch& rb : P.lnred) {
+        if (g_prof) g_prof->begin(9, 0.0);
+        M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
+        if (g_prof) g_prof->end();
+    }
     return 0;
 }
 
@@ -938,6 +983,27 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
     }
     M2F_HIP(hipGraphLaunch(P.gexec, s));
     return 0;
+}
+
+int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream,
+                   int max_entries, int* kinds, float* ms, double* flops) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Profiler prof;
+    prof.s = s;
+    g_prof = &prof;
+    const int r = step_body(*plan, label_smoothing, use_class_weights, normalise, s);
+    g_prof = nullptr;
+    hipError_t e = hipStreamSynchronize(s);
+    const int n = (int)prof.kind.size();
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        if (e == hipSuccess) (void)hipEventElapsedTime(&t, prof.ev[2 * i], prof.ev[2 * i + 1]);
+        if (i < max_entries) { kinds[i] = prof.kind[i]; ms[i] = t; flops[i] = prof.flops[i]; }
+        (void)hipEventDestroy(prof.ev[2 * i]); (void)hipEventDestroy(prof.ev[2 * i + 1]);
+    }
+    if (r) return -1;
+    if (e != hipSuccess) { hipfail(e, "hipStreamSynchronize"); return -1; }
+    return n;
 }
 
 int m2f_rng_advance(uint32_t* rng_state, m2f_stream_t stream) {

@@ -1,0 +1,137 @@
+"""Dialogue-sharded data parallelism (the reference has none: single process, src/train.py:20).
+
+Dialogues are independent units of work (SURVEY.md 8-a fact ii), so each rank (one process per GPU) runs the
+full step on its own dialogues and the only exchange is ONE sum-all-reduce of the flat gradient buffer over
+RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo" on CPU for the tests).
+
+Loss normalisation.  The criterion is a mean over the VALID utterances of the global batch
+(CrossEntropyLoss(ignore_index=-1), src/train.py:48-50).  Averaging per-rank means is wrong when ranks hold
+different valid counts, so each rank back-propagates the gradient of its SUM of per-utterance terms
+(``m2f_step(normalise=0)``); the criterion kernel writes (denominator, numerator) into the tail of the flat
+gradient buffer; after
+the all-reduce every rank holds  sum_r g_r  and  D = sum_r den_r , and the fused Adam kernel divides by D on the
+device (no host sync).  loss = sum_r num_r / D.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+TAIL = 64           # floats appended to the flat gradient buffer: [loss, den, num, 0, ...] written by the criterion kernel
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment; no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_dialogues(n_dialogues: int, rank: int, world: int) -> List[int]:
+    """Rank r owns dialogues r, r+W, r+2W, ... of the global batch (no data-path collective)."""
+    return list(range(rank, n_dialogues, world))
+
+
+class GradReducer:
+    """Sum-all-reduce of [flat gradients | den | num] in `n_buckets` contiguous chunks.
+
+    ``buf`` is the rank's flat gradient buffer extended by TAIL floats.  Chunks are issued in order on the
+    collective's own stream (``async_op=True``), so a caller that produces gradients back-to-front can start
+    reducing finished chunks while the rest is still being computed."""
+
+    def __init__(self, buf: torch.Tensor, n_params: int, group=None, n_buckets: int = 1):
+        assert buf.numel() >= n_params + 3 and buf.dim() == 1
+        self.buf, self.n, self.group = buf, n_params, group
+        n_buckets = max(1, int(n_buckets))
+        edges = [round(i * buf.numel() / n_buckets / 64) * 64 for i in range(n_buckets)] + [buf.numel()]
+        self.chunks = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+        self._work = []
+
+    @property
+    def tail(self) -> torch.Tensor:
+        return self.buf[self.n: self.n + 3]              # (local loss, den, num); den and num are summed
+
+    def set_loss_terms(self, den: torch.Tensor, num: torch.Tensor) -> None:
+        """Only for buffers not filled by a train plan (the plan's criterion kernel writes the tail itself)."""
+        self.buf[self.n + 1: self.n + 2].copy_(den.reshape(1))
+        self.buf[self.n + 2: self.n + 3].copy_(num.reshape(1))
+
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def all_reduce(self, async_op: bool = False) -> None:
+        if self.world() == 1:
+            return
+        self._work = [dist.all_reduce(self.buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                      for a, b in self.chunks]
+        if not async_op:
+            self.wait()
+
+    def wait(self) -> None:
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    @property
+    def global_den(self) -> torch.Tensor:          # device scalar view, feeds m2f_adam_step(grad_scale_ptr)
+        return self.buf[self.n + 1: self.n + 2]
+
+    def global_loss(self) -> torch.Tensor:
+        return self.buf[self.n + 2] / self.buf[self.n + 1]
+
+
+def reduce_metrics(values: Sequence[float], device=None) -> List[float]:
+    """MAX over ranks (timings) - used by bench.py."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if t.device.type == "cpu" and dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.cpu().tolist()
+
+
+class DataParallelStep:
+    """One optimizer step of dialogue-sharded data-parallel training:
+    m2f_step(normalise=0) -> tail <- (den, num) -> all-reduce -> fused Adam with grad_scale = global den."""
+
+    def __init__(self, model, optimizer, group=None, n_buckets: int = 4):
+        self.model, self.optimizer = model, optimizer
+        eng = model.engine()
+        eng.ensure_grad()
+        self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets)
+        optimizer.grad_scale = self.reducer.global_den
+
+    def __call__(self, text, audio, mask, emotion, label_smoothing: float = 0.1, class_weights=None,
+                 use_graph: bool = True) -> torch.Tensor:
+        eng = self.model.engine()
+        B, L = mask.shape
+        plan = eng.plan(B, L, True, self.model.training and self.model.m2f_config.dropout > 0.0)
+        cur = torch.cuda.current_stream(eng.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            plan.set_inputs(text if self.model.text_enabled else None, audio if self.model.audio_enabled else None,
+                            mask, emotion)
+            if class_weights is not None:
+                plan.class_w[: class_weights.numel()].copy_(class_weights)
+            plan.step(label_smoothing, class_weights is not None, False, use_graph)   # tail <- (loss, den, num)
+            self.reducer.all_reduce()
+            eng.publish_grads()
+            self.optimizer.step()
+            loss = self.reducer.global_loss()
+        cur.wait_stream(eng.stream)
+        return loss

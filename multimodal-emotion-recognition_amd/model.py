@@ -138,6 +138,7 @@ class _Engine:
         named = dict(model.named_parameters(remove_duplicate=False))
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_grad: Optional[torch.Tensor] = None
+        self.flat_grad_ext: Optional[torch.Tensor] = None
         self.items = []                       # (param, offset, numel, shape)
         seen = set()
         with torch.no_grad():
@@ -162,7 +163,10 @@ class _Engine:
 
     def ensure_grad(self) -> torch.Tensor:
         if self.flat_grad is None:
-            self.flat_grad = torch.zeros_like(self.flat)
+            from .dp import TAIL
+            # [gradients | den, num, 0...]: the tail rides along in the data-parallel all-reduce (dp.py)
+            self.flat_grad_ext = torch.zeros(self.flat.numel() + TAIL, dtype=torch.float32, device=self.device)
+            self.flat_grad = self.flat_grad_ext[: self.flat.numel()]
             self.grad_views = [self.flat_grad[o: o + n].view(s) for (_, o, n, s) in self.items]
         return self.flat_grad
 
@@ -175,8 +179,9 @@ class _Engine:
                 cfg = M2FConfig(**{**cfg.__dict__, "dropout": 0.0})
             # the C side couples "keeps a backward list" and "dropout active" in its train flag
             train = want_backward or dropout_active
-            grads = self.ensure_grad() if train else None
-            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, grads, self.rng)
+            if train:
+                self.ensure_grad()
+            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng)
             self.plans[key] = pl
         return pl
 

@@ -91,18 +91,26 @@ class FusedAdam(torch.optim.Optimizer):
         eng = self._bind()
         g = self.param_groups[0]
         flat_grad = eng.ensure_grad()
-        for (p, o, n, s), view in zip(eng.items, eng.grad_views):
-            if p.grad is None:
-                view.zero_()
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
+        # fast path: the engine published its flat-buffer views as .grad (checked on the two end parameters);
+        # otherwise gather foreign .grad tensors into the flat buffer first
+        first, last = eng.items[0][0], eng.items[-1][0]
+        if not (first.grad is eng.grad_views[0] and last.grad is eng.grad_views[-1]):
+            for (p, o, n, s), view in zip(eng.items, eng.grad_views):
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
         self._step += 1
         runtime.adam_step(eng.flat, flat_grad, self._m, self._v, self._step, g["lr"], g["betas"], g["eps"],
                           g["weight_decay"], self.grad_scale)
-        self._materialise_state(eng)
-        for p in g["params"]:
-            self.state[p]["step"] = torch.tensor(float(self._step))
         return loss
+
+    def state_dict(self):
+        if self._engine is not None and self._step > 0:
+            self._materialise_state(self._engine)
+            for p in self.param_groups[0]["params"]:
+                self.state[p]["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

@@ -65,6 +65,8 @@ SIGNATURES = {
     "m2f_loss": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),
     "m2f_backward": (c_int, [c_void_p, c_void_p]),
     "m2f_step": (c_int, [c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "m2f_step_timed": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_int),
+                               ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double)]),
     "m2f_rng_advance": (c_int, [c_void_p, c_void_p]),
     "m2f_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_void_p, c_void_p]),
@@ -181,7 +183,13 @@ class Plan:
         self.labels_in = self._view(BUF_LABELS, (self.T,), torch.int64)
         self.class_w = self._view(BUF_CLASSW, (16,), torch.float32)
         self.logits = self._view(BUF_LOGITS, (B, L, C), torch.float32)
-        self.loss = self._view(BUF_LOSS, (4,), torch.float32)
+        if train and grads is not None:
+            # (loss, den, num) live in the tail of the flat gradient buffer (see include/m2fnet_hip.h)
+            assert grads.numel() >= params.numel() + 4, "gradient buffer needs a 64-float tail"
+            self.loss = grads[params.numel(): params.numel() + 4]
+            assert self.loss.data_ptr() == lib().m2f_plan_buffer(self.handle, BUF_LOSS)
+        else:
+            self.loss = self._view(BUF_LOSS, (4,), torch.float32)
         self.dlogits = self._view(BUF_DLOGITS, (B, L, C), torch.float32)
         self.fam0_out = self._view(BUF_FAM0_OUT, (B, L, cfg.d_fam), torch.float32) if cfg.fam_enabled else None
         self.version = 0          # bumped by every forward; backward checks it still owns the activations
@@ -230,6 +238,17 @@ class Plan:
         check(lib().m2f_step(self.handle, label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
                              stream_ptr()), "m2f_step")
         return self.loss
+
+    def step_timed(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True):
+        """One eager step with per-launch hipEvent timing -> list of (kind, ms, algorithmic flops)."""
+        self.version += 1
+        n_max = 4096
+        kinds, ms, fl = (c_int * n_max)(), (c_float * n_max)(), (ctypes.c_double * n_max)()
+        n = lib().m2f_step_timed(self.handle, label_smoothing, int(use_class_weights), int(normalise), stream_ptr(),
+                                 n_max, kinds, ms, fl)
+        if n < 0:
+            raise HipError("m2f_step_timed: " + lib().m2f_last_error().decode())
+        return [(kinds[i], ms[i], fl[i]) for i in range(n)]
 
     def __del__(self):
         h = getattr(self, "handle", None)

@@ -1,0 +1,98 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel exchange: the [gradients | den | num] sum-all-reduce with the
+GLOBAL valid-utterance denominator reproduces the single-process mean-over-valid loss and gradients exactly,
+whereas averaging per-rank means does not.  Local gradients come from the CPU oracle (the HIP path needs a GPU)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import synth
+    import mer_amd  # noqa: F401
+    from mer_amd import dp, layout
+    from oracle import m2fnet_oracle as O
+    r, w, _ = dp.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    cfg, B, L, lengths, kind = synth.CASES["tiny_ragged"]
+    sd = synth.make_state_dict(cfg)
+    text, audio, key_pad, emotion = synth.make_inputs(cfg, B, L, lengths, kind)
+    mine = dp.shard_dialogues(B, rank, world)
+    t, a, kp, em = text[mine], audio[mine], key_pad[mine], emotion[mine]
+    # local SUM-gradient: grad of (mean loss * local den) = what m2f_step(normalise=0) produces
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    logits = O.forward(leaves, cfg, t, a, kp)
+    den = (em != -1).sum().to(torch.float32)
+    local_mean = O.cross_entropy(logits, em)
+    (local_mean * den).backward()
+    specs, total = layout.param_specs(layout.M2FConfig.from_model_config(cfg))
+    buf = torch.zeros(total + dp.TAIL)
+    for sp in specs:
+        buf[sp.offset: sp.offset + sp.numel] = leaves[sp.name].grad.reshape(-1)
+    red = dp.GradReducer(buf, total, n_buckets=3)
+    red.set_loss_terms(den, local_mean.detach() * den)
+    red.all_reduce()
+    g = buf[:total] / red.global_den
+    out = {"loss": float(red.global_loss()), "den": float(red.global_den), "local_mean": float(local_mean)}
+    if rank == 0:
+        _, ref_loss, ref_grads = O.loss_and_grads(sd, cfg, text, audio, key_pad, emotion)
+        worst = 0.0
+        for sp in specs:
+            ref = ref_grads[sp.name].reshape(-1)
+            worst = max(worst, float((g[sp.offset: sp.offset + sp.numel] - ref).abs().max() / ref.abs().max().clamp_min(1e-6)))
+        out.update(ref_loss=float(ref_loss), worst=worst, n_valid=int((emotion != -1).sum()))
+    means = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(means, local_mean.detach().reshape(1))
+    out["mean_of_means"] = float(torch.stack(means).mean())
+    t = dp.reduce_metrics([1.0 + rank])
+    out["max_time"] = t[0]
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_global_denominator():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    r0 = res[0]
+    assert r0["den"] == r0["n_valid"]
+    assert abs(r0["loss"] - r0["ref_loss"]) < 1e-5 and abs(res[1]["loss"] - r0["ref_loss"]) < 1e-5
+    assert r0["worst"] < 1e-4, r0["worst"]
+    assert abs(r0["mean_of_means"] - r0["ref_loss"]) > 1e-4, "ranks hold different valid counts: mean of means differs"
+    assert r0["max_time"] == 2.0 and res[1]["max_time"] == 2.0
+
+
+def test_shard_dialogues_partition():
+    import mer_amd  # noqa: F401
+    from mer_amd import dp
+    for n, w in ((32, 8), (33, 4), (5, 2), (3, 8)):
+        parts = [dp.shard_dialogues(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_reducer_buckets_cover_buffer():
+    import mer_amd  # noqa: F401
+    from mer_amd import dp
+    buf = torch.zeros(10_000 + dp.TAIL)
+    for nb in (1, 3, 8, 64):
+        red = dp.GradReducer(buf, 10_000, n_buckets=nb)
+        assert red.chunks[0][0] == 0 and red.chunks[-1][1] == buf.numel()
+        assert all(a[1] == b[0] for a, b in zip(red.chunks[:-1], red.chunks[1:]))

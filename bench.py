@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--buckets", type=int, default=8)
+    ap.add_argument("--dump-launches", default="", help="write the per-launch timing table (kind, us, GFLOP) to this file")
     args = ap.parse_args()
 
     rank, world, local = dp.init_distributed()
@@ -170,6 +171,12 @@ def main():
     avg_ms = [sum(r[i][1] for r in reps) / len(reps) for i in range(n_l)]
     kinds = [reps[0][i][0] for i in range(n_l)]
     flops = [reps[0][i][2] for i in range(n_l)]
+    if args.dump_launches and rank == 0:
+        names = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "dropout", "ce", "ln_reduce"]
+        with open(args.dump_launches, "w") as f:
+            for i in range(n_l):
+                tf = flops[i] / (avg_ms[i] * 1e-3) / 1e12 if avg_ms[i] > 0 else 0.0
+                f.write(f"{i:4d} {names[kinds[i]]:11s} {avg_ms[i] * 1e3:9.2f} us {flops[i] / 1e9:9.3f} GFLOP {tf:8.1f} TFLOP/s\n")
     gemm_idx = [i for i in range(n_l) if kinds[i] in (0, 1, 2)]
     gemm_ms = sum(avg_ms[i] for i in gemm_idx)
     gemm_fl = sum(flops[i] for i in gemm_idx)
@@ -203,7 +210,11 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            torch.set_num_threads(max(1, os.cpu_count() or 1))
+            try:
+                share = len(os.sched_getaffinity(0))
+            except AttributeError:
+                share = os.cpu_count() or 1
+            torch.set_num_threads(max(1, min(share, 16)))       # the GPU box gives one GPU a 16-core share
             eval_cfg = dict(cfg, dropout=0.0)
             out["cpu_baseline"] = cpu_baseline(eval_cfg, B, L, args.cpu_budget)
         print(json.dumps(out))

@@ -133,7 +133,7 @@ int64_t m2f_attention_probs_elems(int B, int H, int L);
 /* out = (res ? res : 0) + LayerNorm(x) (nn.LayerNorm, eps), stats[T,2] = (mean, rstd). */
 int m2f_layernorm_fwd(int T, int d, const float* x, const float* gamma, const float* beta, const float* res,
                       float* out, float* stats, float eps, m2f_stream_t stream);
-/* dx = LayerNorm backward (+extra); dgamma/dbeta via per-block partials (partial: [ceil(T/16), 2, d]). */
+/* dx = LayerNorm backward (+extra); dgamma/dbeta via per-block partials (partial: [ceil(T/4), 2, d]). */
 int m2f_layernorm_bwd(int T, int d, const float* x, const float* gamma, const float* stats, const float* dy,
                       const float* extra, float* dx, float* partial, float* dgamma, float* dbeta,
                       m2f_stream_t stream);

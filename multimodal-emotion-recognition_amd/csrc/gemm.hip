@@ -29,123 +29,206 @@
 
 namespace {
 
-template <int PREC, bool RC, int BR>
+// ---------------------------------------------------------------------------------------------------------
+// Operand staging: global (fp32) -> registers -> LDS image.
+//   KC operand: element (row, k) at p[row*ld + k];  RC operand: element (row, k) at p[k*ld + row].
+// The staging code is the instruction-issue bottleneck of these small-M GEMMs (measured: ~2 us per k-tile when
+// every element carried its own bounds test and 64-bit address), so:
+//   * per-thread element offsets are computed ONCE per workgroup (rows clamped into range, 32-bit), a k-tile only
+//     adds a wave-uniform base;
+//   * interior tiles (the common case, wave-uniform test) take a path with no masking at all; only edge tiles pay
+//     for per-element predicates;
+//   * every global load is unconditional (edge lanes read a clamped in-range address and are zeroed at store time):
+//     hipcc turns a guarded load into a branch + s_waitcnt vmcnt(0) per load, which serialises the tile fetch
+//     (cdna_hip_programming.md, ".s-level traps" (c));
+//   * nothing consumes a loaded value before store(), so both operands' loads of a k-tile stay in flight while
+//     earlier tiles are multiplied.
+// ---------------------------------------------------------------------------------------------------------
+template <int PREC, bool RC, int BR, int BK_, bool VEC>
 struct Stage {
-    static constexpr int BK = (PREC == M2F_PREC_F32) ? 32 : 64;
-    static constexpr int NT = BR / 32;                                   // staging tasks per thread
-    static constexpr int FPT = (PREC == M2F_PREC_F32) ? 4 : 8;           // floats per task
-    static constexpr int LDR = BR + 1;                                   // F32 row stride (floats)
-    static constexpr int ROWB = BK * 2 + 16;                             // BF16 row stride (bytes)
-    static constexpr int LDS_BYTES = (PREC == M2F_PREC_F32) ? BK * LDR * 4 : BR * ROWB;
+    static constexpr int BK = BK_;
+    static constexpr bool F32 = (PREC == M2F_PREC_F32);
+    // floats per task: F32 4 (one float4) | BF16-KC 8 (8 consecutive k) | BF16-RC 32 (8 k x 4 rows patch)
+    static constexpr int FPT = F32 ? 4 : (RC ? 32 : 8);
+    static constexpr int NT = BR * BK / FPT / 256;                       // staging tasks per thread
+    static_assert(NT >= 1 && (BR * BK) % (FPT * 256) == 0, "tile must split evenly over 256 threads");
+    static constexpr int KCH = BK / (F32 ? 4 : 8);                       // KC: chunks along k per row
+    static constexpr int LDR = BR + 1;                                   // F32 LDS row stride (floats), image [k][row]
+    static constexpr int ROWB = BK * 2 + 16;                             // BF16 LDS row stride (bytes), image [row][k]
+    static constexpr int LDS_BYTES = F32 ? BK * LDR * 4 : BR * ROWB;
 
     float v[NT][FPT];
+    int off[NT];             // element offset of task t at kbase = 0 (row clamped into range)
+    int ld_;                 // leading dimension of the current segment
+    int rows_, row0_, kseg_, kbase_;
+    bool full_;              // tile in flight needs no masking (wave-uniform)
+    int seg_ = -1;           // operand segment the offsets were set up for
 
-    // Loads this thread's share of the [BR x BK] tile at (row0, kbase) of one operand segment.
-    // colsum (RC only, wgrad bias gradient): per-thread running sums over k of the loaded values.
-    __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int rows, int row0,
-                                         int kseg, int kbase, bool vec, bool relu, int tid,
-                                         float* colsum) {
+    // task decomposition (t-th task of this thread)
+    __device__ __forceinline__ static void task_rc(int id, int& r, int& k) {
+        if constexpr (!RC) { r = id / KCH; k = (F32 ? 4 : 8) * (id % KCH); }           // KC: row r, k offset
+        else if constexpr (F32) { constexpr int CH = BR / 4; k = id / CH; r = 4 * (id % CH); }   // float4 along rows
+        else { constexpr int CH = BR / 4; k = 8 * (id / CH); r = 4 * (id % CH); }       // 8 k x 4 rows patch
+    }
+
+    __device__ __forceinline__ void setup(int ld, int rows, int row0, int tid) {
+        ld_ = ld; rows_ = rows; row0_ = row0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int id = tid + 256 * t;
-            if constexpr (PREC == M2F_PREC_F32 && !RC) {
-                const int r = id >> 3, kc = id & 7;
-                const int gr = row0 + r, gk = kbase + 4 * kc;
-                if (vec) {
-                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                    if (gr < rows && gk < kseg) x = *reinterpret_cast<const f32x4*>(p + (size_t)gr * ld + gk);
+            int r, k;
+            task_rc(tid + 256 * t, r, k);
+            int gr = row0 + r;
+            // clamp so that every (vector) load stays inside the operand; clamped lanes are masked at store time
+            const int last = VEC && RC ? rows - 4 : rows - 1;
+            gr = gr < last ? gr : (last > 0 ? last : 0);
+            off[t] = RC ? k * ld + gr : gr * ld + k;
+        }
+    }
+
+    template <bool FULL>
+    __device__ __forceinline__ void issue_impl(const float* __restrict__ pt) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[t][e] = x[e];
-                } else {
+        for (int t = 0; t < NT; ++t) {
+            int r, k;
+            task_rc(threadIdx.x + 256 * t, r, k);
+            if constexpr (!RC) {
+                constexpr int NV = FPT / 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[t][e] = (gr < rows && gk + e < kseg) ? p[(size_t)gr * ld + gk + e] : 0.f;
-                }
-            } else if constexpr (PREC == M2F_PREC_F32 && RC) {
-                constexpr int CH = BR / 4;
-                const int k = id / CH, rc = id % CH;
-                const int gk = kbase + k, gr = row0 + 4 * rc;
-                if (vec) {
-                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                    if (gk < kseg && gr < rows) x = *reinterpret_cast<const f32x4*>(p + (size_t)gk * ld + gr);
+                for (int h = 0; h < NV; ++h) {
+                    if constexpr (VEC) {
+                        int o = off[t] + 4 * h;
+                        if constexpr (!FULL) o = (kbase_ + k + 4 * h < kseg_) ? o : off[t] - k - kbase_;   // row start (k = 0)
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(pt + o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[t][e] = x[e];
-                } else {
+                        for (int e = 0; e < 4; ++e) v[t][4 * h + e] = x[e];
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[t][e] = (gk < kseg && gr + e < rows) ? p[(size_t)gk * ld + gr + e] : 0.f;
-                }
-                if (colsum) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) colsum[e] += v[t][e];
-                }
-            } else if constexpr (PREC == M2F_PREC_BF16 && !RC) {
-                const int r = id >> 3, kc = id & 7;
-                const int gr = row0 + r, gk = kbase + 8 * kc;
-                if (vec) {
-                    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-                    if (gr < rows) {
-                        const float* q = p + (size_t)gr * ld + gk;
-                        if (gk < kseg) x0 = *reinterpret_cast<const f32x4*>(q);
-                        if (gk + 4 < kseg) x1 = *reinterpret_cast<const f32x4*>(q + 4);
+                        for (int e = 0; e < 4; ++e) {
+                            int o = off[t] + 4 * h + e;
+                            if constexpr (!FULL) o = (kbase_ + k + 4 * h + e < kseg_) ? o : off[t] - k - kbase_;
+                            v[t][4 * h + e] = pt[o];
+                        }
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[t][e] = x0[e]; v[t][4 + e] = x1[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[t][e] = (gr < rows && gk + e < kseg) ? p[(size_t)gr * ld + gk + e] : 0.f;
                 }
-            } else {   // BF16, RC: 8 consecutive k of one row; lanes run along the contiguous row dim
-                const int kg = id / BR, r = id % BR;
-                const int gr = row0 + r, gk = kbase + 8 * kg;
+            } else {
+                constexpr int NK = F32 ? 1 : 8;                       // k rows of the patch
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    v[t][e] = (gr < rows && gk + e < kseg) ? p[(size_t)(gk + e) * ld + gr] : 0.f;
-                if (colsum) {
+                for (int j = 0; j < NK; ++j) {
+                    int o = off[t] + j * ld_;
+                    if constexpr (!FULL) o = (kbase_ + k + j < kseg_) ? o : off[t] - (k + kbase_) * ld_;    // k = 0 row
+                    if constexpr (VEC) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(pt + o);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) colsum[0] += v[t][e];
+                        for (int e = 0; e < 4; ++e) v[t][4 * j + e] = x[e];
+                    } else {
+                        // scalar path: clamp each element's row separately (off[] holds the clamped first row)
+                        int grc = row0_ + r;
+                        grc = grc < rows_ - 1 ? grc : rows_ - 1;
+                        const int room = rows_ - 1 - grc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[t][4 * j + e] = pt[o + (e < room ? e : room)];
+                    }
                 }
-            }
-            if (relu) {
-#pragma unroll
-                for (int e = 0; e < FPT; ++e) v[t][e] = fmaxf(v[t][e], 0.f);
             }
         }
     }
 
-    __device__ __forceinline__ void store(char* lds, int tid) const {
+    // Issue the loads of the tile at (kbase) of segment pointer p.  kseg = 0 marks a tile past the end (all masked).
+    __device__ __forceinline__ void issue(const float* __restrict__ p, int kseg, int kbase) {
+        kseg_ = kseg; kbase_ = kbase;
+#ifdef M2F_EXP_NOLOAD
+        full_ = true; return;
+#endif
+        full_ = (row0_ + BR <= rows_) && (kbase + BK <= kseg);
+        const float* pt = p + (RC ? (size_t)kbase * ld_ : (size_t)kbase);
+        if (full_) issue_impl<true>(pt);
+        else issue_impl<false>(pt);
+    }
+
+    __device__ __forceinline__ bool elem_ok(int r, int k) const { return row0_ + r < rows_ && kbase_ + k < kseg_; }
+
+    // Mask (edge tiles only), optional ReLU, optional column sums (wgrad bias gradient), convert, write LDS.
+    template <bool FULL>
+    __device__ __forceinline__ void store_impl(char* lds, bool relu, bool do_cs, f32x4& cs) {
+        if constexpr (!FULL) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int r, k;
+                task_rc(threadIdx.x + 256 * t, r, k);
+#pragma unroll
+                for (int e = 0; e < FPT; ++e) {
+                    bool ok;
+                    if constexpr (!RC) ok = elem_ok(r, k + e);
+                    else ok = elem_ok(r + (e & 3), k + (e >> 2));
+                    v[t][e] = ok ? v[t][e] : 0.f;
+                }
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < FPT; ++e) v[t][e] = fmaxf(v[t][e], 0.f);
+        }
+        if constexpr (RC) {
+            if (do_cs) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < FPT; ++e) cs[e & 3] += v[t][e];
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int id = tid + 256 * t;
-            if constexpr (PREC == M2F_PREC_F32 && !RC) {
-                const int r = id >> 3, kc = id & 7;
+            int r, k;
+            task_rc(threadIdx.x + 256 * t, r, k);
+            if constexpr (F32 && !RC) {
                 float* f = reinterpret_cast<float*>(lds);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[(4 * kc + e) * LDR + r] = v[t][e];
-            } else if constexpr (PREC == M2F_PREC_F32 && RC) {
-                constexpr int CH = BR / 4;
-                const int k = id / CH, rc = id % CH;
+                for (int e = 0; e < 4; ++e) f[(k + e) * LDR + r] = v[t][e];
+            } else if constexpr (F32 && RC) {
                 float* f = reinterpret_cast<float*>(lds);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[k * LDR + 4 * rc + e] = v[t][e];
-            } else {
-                int r, c;
-                if constexpr (!RC) { r = id >> 3; c = id & 7; } else { c = id / BR; r = id % BR; }
+                for (int e = 0; e < 4; ++e) f[k * LDR + r + e] = v[t][e];
+            } else if constexpr (!RC) {
                 bf16x8 h;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[t][e];
-                *reinterpret_cast<bf16x8*>(lds + r * ROWB + c * 16) = h;
+                *reinterpret_cast<bf16x8*>(lds + r * ROWB + k * 2) = h;
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {                     // transpose the 8k x 4rows patch: one b128 per row
+                    bf16x8 h;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[t][4 * j + rr];
+                    *reinterpret_cast<bf16x8*>(lds + (r + rr) * ROWB + k * 2) = h;
+                }
             }
         }
     }
+    __device__ __forceinline__ void store(char* lds, bool relu, bool do_cs, f32x4& cs) {
+#ifdef M2F_EXP_NOSTORE
+        if (v[0][0] == 12345.678f) lds[threadIdx.x] = 1;     // keep the loads alive
+        return;
+#endif
+        if (full_) store_impl<true>(lds, relu, do_cs, cs);
+        else store_impl<false>(lds, relu, do_cs, cs);
+    }
 };
 
-template <int PREC, bool A_RC, bool B_RC, int BM, int BN>
+// LDS-only workgroup barrier: wait for this wave's LDS traffic, then s_barrier.  __syncthreads() carries a
+// workgroup-scope fence for which hipcc also drains vmcnt(0), i.e. the prefetched global loads of the next
+// k-tiles - exactly the loads that must stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC>
 __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
-    using SA = Stage<PREC, A_RC, BM>;
-    using SB = Stage<PREC, B_RC, BN>;
-    constexpr int BK = SA::BK;
+    using SA = Stage<PREC, A_RC, BM, BK, VEC>;
+    using SB = Stage<PREC, B_RC, BN, BK, VEC>;
     constexpr int MI = BM / 64, NI = BN / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -162,7 +245,6 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
     const int tl = (int)blockIdx.x - P.tile_begin;
     const int m0 = (tl / P.tiles_n) * BM, n0 = (tl % P.tiles_n) * BN;
     const uint32_t flags = P.flags;
-    const bool vecA = flags & GF_VEC_A, vecB = flags & GF_VEC_B;
     const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
     const int k0 = P.a.k[0], k1 = P.a.k[1];
     const int nk0 = (k0 + BK - 1) / BK, nk = nk0 + (k1 + BK - 1) / BK;
@@ -170,16 +252,27 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
     char* ldsA = smem;
     char* ldsB = smem + 2 * SA::LDS_BYTES;
 
-    SA sa;
-    SB sb;
-    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // Two register sets: the global loads of k-tile t+2 / t+3 are in flight while tile t is multiplied, so a
+    // workgroup keeps ~2 tiles of HBM/L2 traffic outstanding (these GEMMs are latency-bound, M = B*L is small).
+    SA sa0, sa1;
+    SB sb0, sb1;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f}, cs_unused = {0.f, 0.f, 0.f, 0.f};
     const bool want_bg = A_RC && P.bias_grad != nullptr && n0 == 0;
 
-    auto load_tile = [&](int kt) {
+    // UNCONDITIONAL: a k-tile index past the end issues the same number of loads (all masked to zero at store
+    // time).  A branch around the prefetch would make the number of loads in flight path-dependent, and hipcc then
+    // drains vmcnt to 0 at every store phase (seen in the .s) - no overlap left.
+    auto load_tile = [&](SA& sa, SB& sb, int kt_raw) {
+        const bool tv = kt_raw < nk;
+        const int kt = tv ? kt_raw : 0;
         const int seg = kt >= nk0 ? 1 : 0;
         const int kbase = (seg ? kt - nk0 : kt) * BK;
-        sa.load(P.a.p[seg], P.a.ld[seg], M, m0, P.a.k[seg], kbase, vecA, reluA, tid, want_bg ? colsum : nullptr);
-        sb.load(P.b.p[seg], P.b.ld[seg], N, n0, P.b.k[seg], kbase, vecB, reluB, tid, nullptr);
+        if (sa.seg_ != seg) {                                  // wave-uniform, at most twice per workgroup
+            sa.setup(P.a.ld[seg], M, m0, tid); sa.seg_ = seg;
+            sb.setup(P.b.ld[seg], N, n0, tid); sb.seg_ = seg;
+        }
+        sa.issue(P.a.p[seg], tv ? P.a.k[seg] : 0, kbase);
+        sb.issue(P.b.p[seg], tv ? P.b.k[seg] : 0, kbase);
     };
 
     f32x16 acc[MI][NI];
@@ -190,16 +283,10 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    sa.store(ldsA, tid);
-    sb.store(ldsB, tid);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);                       // global loads in flight under the MFMAs
-
+    auto compute = [&](int cur) {
+#ifdef M2F_EXP_NOCOMPUTE
+        return;
+#endif
         const char* a_l = ldsA + cur * SA::LDS_BYTES;
         const char* b_l = ldsB + cur * SB::LDS_BYTES;
         if constexpr (PREC == M2F_PREC_F32) {
@@ -236,38 +323,45 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+    };
 
-        if (more) {
-            sa.store(ldsA + (cur ^ 1) * SA::LDS_BYTES, tid);
-            sb.store(ldsB + (cur ^ 1) * SB::LDS_BYTES, tid);
-        }
-        __syncthreads();
+    load_tile(sa0, sb0, 0);
+    load_tile(sa1, sb1, 1);
+    sa0.store(ldsA, reluA, want_bg, colsum);
+    sb0.store(ldsB, reluB, false, cs_unused);
+    lds_barrier();
+    load_tile(sa0, sb0, 2);
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even phase: multiply tile kt (buffer 0); stage tile kt+1 (register set 1) into buffer 1
+        compute(0);
+        // (stores are unconditional too: past the last tile they write the all-zero masked tile to an unused buffer)
+        sa1.store(ldsA + SA::LDS_BYTES, reluA, want_bg, colsum);
+        sb1.store(ldsB + SB::LDS_BYTES, reluB, false, cs_unused);
+        lds_barrier();
+        load_tile(sa1, sb1, kt + 3);
+        if (kt + 1 >= nk) break;
+        // odd phase: multiply tile kt+1 (buffer 1); stage tile kt+2 (register set 0) into buffer 0
+        compute(1);
+        sa0.store(ldsA, reluA, want_bg, colsum);
+        sb0.store(ldsB, reluB, false, cs_unused);
+        lds_barrier();
+        load_tile(sa0, sb0, kt + 4);
     }
 
     // ---- wgrad: bias gradient = column sums of the A operand (dY) over the reduction dim ----------
     if constexpr (A_RC) {
         if (want_bg) {      // block-uniform
             float* red = reinterpret_cast<float*>(smem);
-            if constexpr (PREC == M2F_PREC_F32) {
-                constexpr int CH = BM / 4, G = 256 / CH;
-                const int g = tid / CH, rc = tid % CH;
+            constexpr int CH = BM / 4, G = 256 / CH;       // thread = (k-group g, 4 rows 4*rc..): same rows for all its tasks
+            const int g = tid / CH, rc = tid % CH;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) red[g * BM + 4 * rc + e] = colsum[e];
-                __syncthreads();
-                if (tid < BM) {
-                    float s = 0.f;
-                    for (int q = 0; q < G; ++q) s += red[q * BM + tid];
-                    if (m0 + tid < M) P.bias_grad[m0 + tid] = s;
-                }
-            } else {
-                constexpr int G = 256 / BM;
-                red[(tid / BM) * BM + (tid % BM)] = colsum[0];
-                __syncthreads();
-                if (tid < BM) {
-                    float s = 0.f;
-                    for (int q = 0; q < G; ++q) s += red[q * BM + tid];
-                    if (m0 + tid < M) P.bias_grad[m0 + tid] = s;
-                }
+            for (int e = 0; e < 4; ++e) red[g * BM + 4 * rc + e] = colsum[e];
+            __syncthreads();
+            if (tid < BM) {
+                float sum = 0.f;
+                for (int q = 0; q < G; ++q) sum += red[q * BM + tid];
+                if (m0 + tid < M) P.bias_grad[m0 + tid] = sum;
             }
         }
     }
@@ -288,31 +382,42 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            const float bv = (bias && col < N) ? bias[col] : 0.f;
+            const bool col_ok = col < N;
+            const int colc = col_ok ? col : 0;
+            const float bv = bias ? bias[colc] : 0.f;
+            const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+            // all side loads first (unconditional, clamped), then the arithmetic, then predicated stores
+            float rv[16], gv[16], cv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M && col < N) {
-                    float v = acc[i][j][r] + bv;
-                    if (relu_out) v = fmaxf(v, 0.f);
-                    if (site) v = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? v * gb.drop_scale : 0.f;
-                    if (res) v += res[(size_t)row * ldres + col];
-                    if (gate) v = gate[(size_t)row * ldgate + col] > 0.f ? v * gscale : 0.f;
-                    float* dst = C + (size_t)row * ldc + col;
-                    if (accum) v += *dst;
-                    *dst = v;
-                }
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                const int rowc = row < M ? row : 0;
+                rv[r] = res ? res[(size_t)rowc * ldres + colc] : 0.f;
+                gv[r] = gate ? gate[(size_t)rowc * ldgate + colc] : 1.f;
+                cv[r] = accum ? C[(size_t)rowc * ldc + colc] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bv;
+                if (relu_out) v = fmaxf(v, 0.f);
+                if (site) v = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? v * gb.drop_scale : 0.f;
+                v += rv[r];
+                if (gate) v = gv[r] > 0.f ? v * gscale : 0.f;
+                v += cv[r];
+                if (row < M && col_ok) C[(size_t)row * ldc + col] = v;
             }
         }
     }
 }
 
-template <int PREC, bool A_RC, bool B_RC, int BM, int BN>
+template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC>
 hipError_t launch_cfg(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
-    using SA = Stage<PREC, A_RC, BM>;
-    using SB = Stage<PREC, B_RC, BN>;
+    using SA = Stage<PREC, A_RC, BM, BK, VEC>;
+    using SB = Stage<PREC, B_RC, BN, BK, VEC>;
     constexpr int lds = 2 * SA::LDS_BYTES + 2 * SB::LDS_BYTES;
-    auto kern = m2f_gemm_kernel<PREC, A_RC, B_RC, BM, BN>;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = m2f_gemm_kernel<PREC, A_RC, B_RC, BM, BN, BK, VEC>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -342,8 +447,18 @@ hipError_t launch_tile(GemmBatch& gb, int tile, hipStream_t stream) {
         t += m2f_cdiv(gb.pr[i].M, bm) * gb.pr[i].tiles_n;
     }
     if (t == 0) return hipSuccess;
-    if (tile == 128) return launch_cfg<PREC, A_RC, B_RC, 128, 128>(gb, t, stream);
-    return launch_cfg<PREC, A_RC, B_RC, 64, 64>(gb, t, stream);
+    // k-tile depth: 64x64 tiles stage 128 (bf16) / 64 (fp32) deep, 128x128 tiles half that (register budget)
+    constexpr int BK64 = (PREC == M2F_PREC_F32) ? 64 : 128;
+    constexpr int BK128 = (PREC == M2F_PREC_F32) ? 32 : 64;
+    // 16-byte loads only when every operand of every problem of the launch allows them
+    bool vec = true;
+    for (int i = 0; i < gb.count; ++i)
+        vec = vec && (gb.pr[i].flags & GF_VEC_A) && (gb.pr[i].flags & GF_VEC_B);
+    if (tile == 128)
+        return vec ? launch_cfg<PREC, A_RC, B_RC, 128, 128, BK128, true>(gb, t, stream)
+                   : launch_cfg<PREC, A_RC, B_RC, 128, 128, BK128, false>(gb, t, stream);
+    return vec ? launch_cfg<PREC, A_RC, B_RC, 64, 64, BK64, true>(gb, t, stream)
+               : launch_cfg<PREC, A_RC, B_RC, 64, 64, BK64, false>(gb, t, stream);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -108,7 +108,7 @@ struct LnBatch {
     float eps;
     const uint32_t* rng; uint32_t drop_thresh; float drop_scale;
 };
-#define M2F_LN_ROWS_PER_BLOCK 16
+#define M2F_LN_ROWS_PER_BLOCK 4
 hipError_t m2f_launch_ln_fwd(LnBatch& lb, hipStream_t stream);
 hipError_t m2f_launch_ln_bwd(LnBatch& lb, hipStream_t stream);
 static inline int m2f_ln_row_blocks(int T) { return (T + M2F_LN_ROWS_PER_BLOCK - 1) / M2F_LN_ROWS_PER_BLOCK; }

@@ -91,7 +91,7 @@ def layernorm_bwd(x, gamma, stats, dy, extra: Optional[torch.Tensor] = None):
     runtime.require_gpu()
     T, d = x.shape
     dx = torch.empty_like(x)
-    partial = torch.empty((T + 15) // 16, 2, d, dtype=torch.float32, device=x.device)
+    partial = torch.empty((T + 3) // 4, 2, d, dtype=torch.float32, device=x.device)
     dg = torch.empty(d, dtype=torch.float32, device=x.device)
     db = torch.empty(d, dtype=torch.float32, device=x.device)
     check(lib().m2f_layernorm_bwd(T, d, ptr(x), ptr(gamma), ptr(stats), ptr(dy), ptr(extra), ptr(dx), ptr(partial),

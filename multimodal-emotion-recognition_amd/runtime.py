@@ -18,7 +18,7 @@ from .layout import M2FConfig, param_specs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libm2fnet_hip.so")
+LIB_PATH = os.environ.get("M2F_LIB", os.path.join(CSRC, "libm2fnet_hip.so"))   # M2F_LIB: experiment builds only
 HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "include", "m2fnet_hip.h"))
 
 F32, BF16 = 0, 1

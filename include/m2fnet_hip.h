@@ -118,7 +118,10 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1,
              float* c, int ldc, const float* bias, const float* res, int ldres,
              const float* gate, int ldgate, float gate_scale, float* bias_grad,
              int relu_a, int relu_b, int relu_out, int accumulate,
-             uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile, m2f_stream_t stream);
+             uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile,
+             float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles, m2f_stream_t stream);
+/* splitk_ws / splitk_tickets (nullable): scratch for in-launch split-K of launches too small to fill the chip:
+ * splitk_max_tiles * 4 * 64*64 floats and splitk_max_tiles ZEROED uint32 tickets (re-armed by the kernel). */
 /* softmax(q k^T / sqrt(hd) + key_padding_mask) v per (dialogue, head) (nn.MultiheadAttention inside
  * src/model.py:8,14,61,73); probs receives P^T per head, padded to Lp = 16*ceil(L/16). */
 int m2f_attention_fwd(int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk,

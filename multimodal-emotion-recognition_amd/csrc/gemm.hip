@@ -242,12 +242,16 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
     const GemmProblem& P = gb.pr[pi];
 
     const int M = P.M, N = P.N;
-    const int tl = (int)blockIdx.x - P.tile_begin;
+    // split-K: `splitk` consecutive workgroups share one output tile, each reduces a slice of the k-tile list
+    const int S = P.splitk;
+    const int tb = (int)blockIdx.x - P.tile_begin;
+    const int tl = tb / S, slice = tb - tl * S;
     const int m0 = (tl / P.tiles_n) * BM, n0 = (tl % P.tiles_n) * BN;
     const uint32_t flags = P.flags;
     const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
     const int k0 = P.a.k[0], k1 = P.a.k[1];
-    const int nk0 = (k0 + BK - 1) / BK, nk = nk0 + (k1 + BK - 1) / BK;
+    const int nk0 = (k0 + BK - 1) / BK, nk_all = nk0 + (k1 + BK - 1) / BK;
+    const int kt_begin = (slice * nk_all) / S, nk = ((slice + 1) * nk_all) / S - kt_begin;   // this slice: nk k-tiles
 
     char* ldsA = smem;
     char* ldsB = smem + 2 * SA::LDS_BYTES;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
     // drains vmcnt to 0 at every store phase (seen in the .s) - no overlap left.
     auto load_tile = [&](SA& sa, SB& sb, int kt_raw) {
         const bool tv = kt_raw < nk;
-        const int kt = tv ? kt_raw : 0;
+        const int kt = tv ? kt_begin + kt_raw : 0;
         const int seg = kt >= nk0 ? 1 : 0;
         const int kbase = (seg ? kt - nk0 : kt) * BK;
         if (sa.seg_ != seg) {                                  // wave-uniform, at most twice per workgroup
@@ -366,6 +370,48 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
         }
     }
 
+    // ---- split-K: publish the partial tile; the LAST arriving slice sums all partials (fixed order -> bitwise
+    // reproducible) and runs the epilogue.  Agent-scope release/acquire around a relaxed ticket, valid for any
+    // placement of the slices over CUs / XCDs (cdna_hip_programming.md, "In-launch split-K reduction").
+    if (S > 1) {
+        static_assert(MI * NI * 16 * 256 == BM * BN, "slab layout");
+        float* slab = gb.splitk_ws + (size_t)(P.slab_begin + tl * S) * (BM * BN);
+        float* mine = slab + (size_t)slice * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((i * NI + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(gb.splitk_cnt + P.cnt_begin + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (t == (unsigned)(S - 1)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*flag == 0) return;                              // block-uniform
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(gb.splitk_cnt + P.cnt_begin + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sum = 0.f;
+                    for (int q = 0; q < S; ++q) sum += slab[(size_t)q * (BM * BN) + ((i * NI + j) * 16 + r) * 256 + tid];
+                    acc[i][j][r] = sum;
+                }
+    }
+
     // ---- fused epilogue ---------------------------------------------------------------------------
     const float* bias = P.bias;
     const float* res = P.res;
@@ -440,16 +486,43 @@ hipError_t launch_tile(GemmBatch& gb, int tile, hipStream_t stream) {
     };
     if (tile == 0) tile = (count_tiles(128, 128) >= 512) ? 128 : 64;     // fill 256 CUs first
     const int bm = tile, bn = tile;
-    int t = 0;
-    for (int i = 0; i < gb.count; ++i) {
-        gb.pr[i].tile_begin = t;
-        gb.pr[i].tiles_n = m2f_cdiv(gb.pr[i].N, bn);
-        t += m2f_cdiv(gb.pr[i].M, bm) * gb.pr[i].tiles_n;
-    }
-    if (t == 0) return hipSuccess;
-    // k-tile depth: 64x64 tiles stage 128 (bf16) / 64 (fp32) deep, 128x128 tiles half that (register budget)
     constexpr int BK64 = (PREC == M2F_PREC_F32) ? 64 : 128;
     constexpr int BK128 = (PREC == M2F_PREC_F32) ? 32 : 64;
+    const int bk = tile == 128 ? BK128 : BK64;
+    // split-K when the launch cannot occupy the chip: a CU pulls operands at a fixed ~25-45 GB/s (L1 miss queue x
+    // latency), so small grids are spread over more CUs.  Only for the forward / dgrad forms on 64x64 tiles.
+    int want_s = 1;
+    const int plain = count_tiles(bm, bn);
+    if (tile == 64 && !A_RC && gb.splitk_ws && gb.splitk_cnt && plain > 0 && plain < 224) {
+        want_s = (352 + plain - 1) / plain;
+        if (want_s > 4) want_s = 4;
+    }
+    int t = 0, slabs = 0, tiles_total = 0;
+    for (int i = 0; i < gb.count; ++i) {
+        GemmProblem& p = gb.pr[i];
+        const int nk = m2f_cdiv(p.a.k[0], bk) + m2f_cdiv(p.a.k[1], bk);
+        int sp = want_s;
+        if (sp > nk / 2) sp = nk / 2;                 // at least two k-tiles per slice
+        if (sp < 1) sp = 1;
+        p.splitk = sp;
+        p.tile_begin = t;
+        p.slab_begin = slabs;                         // in slices (one [BM x BN] partial each)
+        p.cnt_begin = tiles_total;
+        p.tiles_n = m2f_cdiv(p.N, bn);
+        const int tiles = m2f_cdiv(p.M, bm) * p.tiles_n;
+        t += tiles * sp;
+        slabs += tiles * sp;
+        tiles_total += tiles;
+    }
+    if (want_s > 1 && (tiles_total > gb.splitk_max_tiles || slabs > 4 * gb.splitk_max_tiles)) {   // scratch too small: no split
+        t = 0;
+        for (int i = 0; i < gb.count; ++i) {
+            GemmProblem& p = gb.pr[i];
+            p.splitk = 1; p.tile_begin = t; p.slab_begin = 0; p.cnt_begin = 0;
+            t += m2f_cdiv(p.M, bm) * p.tiles_n;
+        }
+    }
+    if (t == 0) return hipSuccess;
     // 16-byte loads only when every operand of every problem of the launch allows them
     bool vec = true;
     for (int i = 0; i < gb.count; ++i)

@@ -40,6 +40,7 @@ struct GemmProblem {
     uint32_t drop_site;       // 0 = no dropout in the epilogue
     uint32_t flags;
     int tile_begin, tiles_n;  // filled by the launcher
+    int splitk, slab_begin, cnt_begin;   // filled by the launcher (k-slices per tile, first partial slab, first ticket)
 };
 
 #define M2F_GEMM_MAX_PROBLEMS 8
@@ -49,7 +50,13 @@ struct GemmBatch {
     const uint32_t* rng;      // dropout RNG state (device), may be null when no problem has drop_site
     uint32_t drop_thresh;     // p * 2^32
     float drop_scale;         // 1 / (1 - p)
+    // split-K scratch (optional; null = never split): partial-tile slabs [splitk_max_tiles * 4][64*64] floats and one
+    // zero-initialised ticket per tile (the last arriver re-arms it)
+    float* splitk_ws;
+    unsigned* splitk_cnt;
+    int splitk_max_tiles;
 };
+#define M2F_SPLITK_MAX_TILES 512
 
 // Launches one grouped GEMM. Returns hipSuccess or the launch error. `tile` = 0 (auto), 64 or 128.
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream);

@@ -149,6 +149,7 @@ struct Op {
     std::vector<AttnProblem> ap;
     std::vector<LnProblem> lp;
     float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;      // OP_DROPOUT
+    std::vector<std::pair<int, int>> src;       // (chain id, index in that chain) of the ops merged into this one
 };
 
 struct Launch {
@@ -158,6 +159,7 @@ struct Launch {
     AttnBatch ab;
     LnBatch lb;
     float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;
+    std::vector<std::pair<int, int>> src;
 };
 
 struct Arena {
@@ -215,13 +217,26 @@ struct m2f_plan {
     void* bufs[M2F_BUF_COUNT] = {nullptr};
     float* loss_terms = nullptr;
     std::vector<Launch> fwd, bwd;
+    // deferred weight-gradient launches run on a second stream, each as soon as the chain launch that produces its last
+    // operand has been issued (wg_dep = index into bwd, -1 = operands come from the forward pass / criterion)
+    std::vector<Launch> wg;
+    std::vector<int> wg_dep;
+    hipStream_t aux = nullptr;
+    std::vector<hipEvent_t> wg_ev;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<LnReduceBatch> lnred;
     size_t ws_used = 0;
     // graph cache for m2f_step
     hipGraphExec_t gexec = nullptr;
     float g_ls = 0.f; int g_cw = -1, g_norm = -1;
     bool warmed = false;          // one eager step (sets kernel attributes) before the first capture
-    ~m2f_plan() { if (gexec) (void)hipGraphExecDestroy(gexec); }
+    ~m2f_plan() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        for (hipEvent_t e : wg_ev) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (aux) (void)hipStreamDestroy(aux);
+    }
 };
 
 namespace {
@@ -234,6 +249,8 @@ struct Builder {
     std::vector<Op> br_f[2], br_b[2];          // per-branch (0 audio, 1 text) forward / backward chains
     std::vector<Op> chain_b;                   // classifier + FAM backward (before the branches)
     std::vector<GemmProblem> wgrads;           // deferred weight-gradient problems (TN)
+    std::vector<std::pair<int, int>> wdeps;    // per wgrad problem: (chain id, index) of the last op emitted before it
+    int cur_chain = 2;                         // chain being built: 0 audio branch, 1 text branch, 2 head (chain_b)
     std::vector<LnReduceItem> lnitems;
     ModBuf mod[2];
     std::vector<FamBuf> fam;
@@ -277,6 +294,8 @@ struct Builder {
         if (b_off >= 0) p.bias_grad = G((size_t)b_off);
         if (relu_b) p.flags |= GF_RELU_B;
         wgrads.push_back(p);
+        const std::vector<Op>& cur = cur_chain == 2 ? chain_b : br_b[cur_chain];
+        wdeps.push_back({cur_chain, (int)cur.size() - 1});
     }
 
     // ---------------- modality branch: encoders + projection --------------------------------------
@@ -360,9 +379,14 @@ struct Builder {
         ModBuf& m = mod[bi];
         const int d = m.d, H = m.H, nl = m.nl, nt = m.nt, F = P.cfg.dim_ff, E = P.cfg.d_fam;
         std::vector<Op>& bw = br_b[bi];
+        const int saved_chain = cur_chain;
+        {   // the projection wgrad reads d(xp), produced by the head chain (everything emitted so far)
+            cur_chain = 2;
+        }
         const float* x_last = nt > 0 ? m.xe[nt - 1] : m.x_in;
         wgrad(dxp, E, x_last, d, E, d, mp.proj_w, d, (long)mp.proj_b);
-        if (nt == 0) return;
+        cur_chain = bi;
+        if (nt == 0) { cur_chain = saved_chain; return; }
         float* dx = ar.f((size_t)T * d);
         {
             GemmProblem g = gp_make(dxp, E, W(mp.proj_w), d, T, d, E, dx, d);
@@ -437,6 +461,7 @@ struct Builder {
             }
             dxe = gy;
         }
+        cur_chain = saved_chain;
     }
 
     // ---------------- fusion stack + classifier ------------------------------------------------------
@@ -670,6 +695,7 @@ bool compatible(const Op& a, const Op& b) {
 }
 Op merged(const Op& a, const Op& b) {
     Op o = a;
+    o.src.insert(o.src.end(), b.src.begin(), b.src.end());
     o.gp.insert(o.gp.end(), b.gp.begin(), b.gp.end());
     o.ap.insert(o.ap.end(), b.ap.begin(), b.ap.end());
     o.lp.insert(o.lp.end(), b.lp.begin(), b.lp.end());
@@ -701,13 +727,16 @@ std::vector<Op> merge_chains(const std::vector<Op>& A, const std::vector<Op>& B)
 void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Launch>& out) {
     for (const Op& o : ops) {
         Launch l;
-        l.kind = o.kind; l.layout = o.layout;
+        l.kind = o.kind; l.layout = o.layout; l.src = o.src;
         memset(&l.gb, 0, sizeof(l.gb)); memset(&l.ab, 0, sizeof(l.ab)); memset(&l.lb, 0, sizeof(l.lb));
         switch (o.kind) {
             case OP_GEMM:
                 l.gb.count = (int)o.gp.size();
                 for (size_t i = 0; i < o.gp.size(); ++i) l.gb.pr[i] = o.gp[i];
                 l.gb.rng = P.rng; l.gb.drop_thresh = P.drop_thresh; l.gb.drop_scale = P.drop_scale;
+                // in-launch split-K stays OFF in plans: measured 2x SLOWER on the 96-tile GEMMs (the agent-scope
+                // release/acquire seam costs more than the spread saves; same verdict as the guide's M=256 block)
+                l.gb.splitk_ws = nullptr; l.gb.splitk_cnt = nullptr; l.gb.splitk_max_tiles = 0;
                 break;
             case OP_ATTN_FWD: case OP_ATTN_BWD:
                 l.ab.count = (int)o.ap.size();
@@ -751,16 +780,35 @@ int build_plan(m2f_plan& P, char* ws_base) {
     to_launches(P, merge_chains(bld.br_f[0], bld.br_f[1]), P.fwd);
     to_launches(P, bld.chain_f, P.fwd);
     if (P.train) {
+        for (size_t i = 0; i < bld.chain_b.size(); ++i) bld.chain_b[i].src.push_back({2, (int)i});
+        for (int b = 0; b < 2; ++b)
+            for (size_t i = 0; i < bld.br_b[b].size(); ++i) bld.br_b[b][i].src.push_back({b, (int)i});
         to_launches(P, bld.chain_b, P.bwd);
         to_launches(P, merge_chains(bld.br_b[0], bld.br_b[1]), P.bwd);
-        // deferred weight gradients: chip-filling grouped launches
+        // where did (chain, index) end up in the final launch order?
+        auto final_index = [&](std::pair<int, int> tag) {
+            if (tag.second < 0) return tag.first == 2 ? -1 : (int)bld.chain_b.size() - 1;   // before the branch: after the head
+            for (size_t i = 0; i < P.bwd.size(); ++i)
+                for (const auto& sidx : P.bwd[i].src)
+                    if (sidx == tag) return (int)i;
+            return (int)P.bwd.size() - 1;
+        };
+        // deferred weight gradients: chip-filling grouped launches, in dependency order
+        std::vector<std::pair<int, size_t>> order;
+        for (size_t i = 0; i < bld.wgrads.size(); ++i) order.push_back({final_index(bld.wdeps[i]), i});
+        std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         std::vector<Op> wops;
-        for (size_t i = 0; i < bld.wgrads.size(); i += M2F_GEMM_MAX_PROBLEMS) {
+        for (size_t i = 0; i < order.size(); i += M2F_GEMM_MAX_PROBLEMS) {
             Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
-            for (size_t j = i; j < std::min(bld.wgrads.size(), i + M2F_GEMM_MAX_PROBLEMS); ++j) o.gp.push_back(bld.wgrads[j]);
+            int dep = -1;
+            for (size_t j = i; j < std::min(order.size(), i + M2F_GEMM_MAX_PROBLEMS); ++j) {
+                o.gp.push_back(bld.wgrads[order[j].second]);
+                dep = std::max(dep, order[j].first);
+            }
             wops.push_back(o);
+            P.wg_dep.push_back(dep);
         }
-        to_launches(P, wops, P.bwd);
+        to_launches(P, wops, P.wg);
         for (size_t i = 0; i < bld.lnitems.size(); i += M2F_LNRED_MAX_ITEMS) {
             LnReduceBatch rb;
             memset(&rb, 0, sizeof(rb));
@@ -800,8 +848,9 @@ double attn_flops(const AttnBatch& ab, bool bwd) {
     return f;
 }
 
-int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s) {
-    for (Launch& l : ls) {
+int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s, size_t first = 0, size_t count = (size_t)-1) {
+    for (size_t li = first; li < ls.size() && li - first < count; ++li) {
+        Launch& l = ls[li];
         hipError_t e = hipSuccess;
         if (g_prof) {
             int k = l.kind == OP_GEMM ? l.layout : (l.kind + 2);     // 0..2 gemm NT/NN/TN, 3 attn fwd, 4 attn bwd, 5 ln fwd, 6 ln bwd, 7 dropout
@@ -840,7 +889,31 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
 
 int do_backward(m2f_plan& P, hipStream_t s) {
     if (!P.train || !P.grads) return fail("m2f_backward: plan was created without train=1 / gradient buffer");
-    if (int r = run_launches(P, P.bwd, s)) return r;
+    const bool overlap = P.aux != nullptr && g_prof == nullptr && !P.wg.empty();
+    if (!overlap) {                                  // serial: chain, then the weight gradients (per-launch timing mode)
+        if (int r = run_launches(P, P.bwd, s)) return r;
+        if (int r = run_launches(P, P.wg, s)) return r;
+    } else {
+        // fork: the aux stream sees everything issued so far (forward activations, dlogits)
+        M2F_HIP(hipEventRecord(P.ev_fork, s));
+        M2F_HIP(hipStreamWaitEvent(P.aux, P.ev_fork, 0));
+        size_t g = 0;
+        for (; g < P.wg.size() && P.wg_dep[g] < 0; ++g)
+            if (int r = run_launches(P, P.wg, P.aux, g, 1)) return r;
+        for (size_t i = 0; i < P.bwd.size(); ++i) {
+            if (int r = run_launches(P, P.bwd, s, i, 1)) return r;
+            if (g < P.wg.size() && P.wg_dep[g] <= (int)i) {
+                M2F_HIP(hipEventRecord(P.wg_ev[g], s));
+                M2F_HIP(hipStreamWaitEvent(P.aux, P.wg_ev[g], 0));
+                for (; g < P.wg.size() && P.wg_dep[g] <= (int)i; ++g)
+                    if (int r = run_launches(P, P.wg, P.aux, g, 1)) return r;
+            }
+        }
+        for (; g < P.wg.size(); ++g)
+            if (int r = run_launches(P, P.wg, P.aux, g, 1)) return r;
+        M2F_HIP(hipEventRecord(P.ev_join, P.aux));
+        M2F_HIP(hipStreamWaitEvent(s, P.ev_join, 0));
+    }
     for (const LnReduceBatch& rb : P.lnred) {
         if (g_prof) g_prof->begin(9, 0.0);
         M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
@@ -921,6 +994,15 @@ m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, in
     }
     p->params = params; p->grads = grads; p->rng = rng_state;
     build_plan(*p, static_cast<char*>(workspace));
+    if (train && !p->wg.empty()) {
+        bool ok = hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
+        p->wg_ev.resize(p->wg.size(), nullptr);
+        for (size_t i = 0; ok && i < p->wg.size(); ++i)
+            ok = hipEventCreateWithFlags(&p->wg_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { fail("could not create the auxiliary stream / events"); delete p; return nullptr; }
+    }
     if ((int64_t)p->ws_used > workspace_bytes) {
         fail("workspace too small: need " + std::to_string(p->ws_used) + " bytes");
         delete p;
@@ -939,7 +1021,7 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (phase == 0) return (int)plan->fwd.size();
     if (phase == 1) return 2;
-    return (int)(plan->bwd.size() + plan->lnred.size());
+    return (int)(plan->bwd.size() + plan->wg.size() + plan->lnred.size());
 }
 
 int m2f_forward(m2f_plan* plan, m2f_stream_t stream) {
@@ -1028,7 +1110,7 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
              const float* b0, int ldb0, const float* b1, int ldb1, float* c, int ldc, const float* bias, const float* res,
              int ldres, const float* gate, int ldgate, float gate_scale, float* bias_grad, int relu_a, int relu_b,
              int relu_out, int accumulate, uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile,
-             m2f_stream_t stream) {
+             float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles, m2f_stream_t stream) {
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     GemmProblem p = gp_make(a0, lda0, b0, ldb0, M, N, K0, c, ldc);
@@ -1037,6 +1119,7 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
     p.bias_grad = bias_grad; p.drop_site = drop_site;
     p.flags = (relu_a ? GF_RELU_A : 0) | (relu_b ? GF_RELU_B : 0) | (relu_out ? GF_RELU_OUT : 0) | (accumulate ? GF_ACCUM : 0);
     gb.pr[0] = p; gb.count = 1; gb.rng = rng_state;
+    gb.splitk_ws = splitk_ws; gb.splitk_cnt = splitk_tickets; gb.splitk_max_tiles = splitk_ws && splitk_tickets ? splitk_max_tiles : 0;
     if (drop_site) drop_params(drop_p, &gb.drop_thresh, &gb.drop_scale);
     M2F_HIP(m2f_launch_gemm(gb, precision, layout, tile, static_cast<hipStream_t>(stream)));
     return 0;

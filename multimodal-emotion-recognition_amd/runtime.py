@@ -72,7 +72,8 @@ SIGNATURES = {
                               c_float, c_int, c_void_p, c_void_p]),
     "m2f_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                          c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float,
-                         c_void_p, c_int, c_int, c_int, c_int, c_uint32, c_float, c_void_p, c_int, c_void_p]),
+                         c_void_p, c_int, c_int, c_int, c_int, c_uint32, c_float, c_void_p, c_int, c_void_p, c_void_p,
+                         c_int, c_void_p]),
     "m2f_attention_fwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_void_p, c_uint32, c_float, c_void_p, c_void_p]),
     "m2f_attention_bwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,

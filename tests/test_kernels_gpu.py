@@ -48,6 +48,28 @@ def test_gemm_layouts(prec, tile, shape):
 
 
 @pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
+@pytest.mark.parametrize("shape", [(512, 768, 768), (512, 7, 768), (100, 130, 2048), (64, 64, 512)])
+def test_gemm_split_k_matches_unsplit_and_is_reproducible(prec, shape):
+    """Small launches are split along K inside the launch (last-arriver reduce); results must equal the unsplit
+    kernel up to summation order, be bitwise reproducible run to run, and keep the fused epilogue."""
+    M, N, K = shape
+    a, b, bias, res = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3), _rand(M, N, seed=4)
+    ref = torch.relu(a.double() @ b.double().t() + bias.double()) + res.double()
+    outs = [F.gemm(a, b, F.NT, prec, bias=bias, res=res, relu_out=True, tile=64, split_k=True) for _ in range(4)]
+    _close(outs[0].double(), ref, TOL[prec], "split-K NT")
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "split-K must be bitwise reproducible (fixed-order reduce)"
+    plain = F.gemm(a, b, F.NT, prec, bias=bias, res=res, relu_out=True, tile=64, split_k=False)
+    _close(outs[0].double(), plain.double(), 1e-5 if prec == runtime.F32 else 1e-5, "split vs unsplit")
+    bt = b.t().contiguous()
+    _close(F.gemm(a, bt, F.NN, prec, tile=64, split_k=True).double(), a.double() @ b.double().t(), TOL[prec], "split-K NN")
+    # two-segment operand under split-K
+    a2, b2 = _rand(M, 256, seed=5), _rand(N, 256, seed=6)
+    got = F.gemm(a, b, F.NT, prec, a1=a2, b1=b2, tile=64, split_k=True)
+    _close(got.double(), a.double() @ b.double().t() + a2.double() @ b2.double().t(), TOL[prec], "split-K two segments")
+
+
+@pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
 def test_gemm_epilogue_and_segments(prec):
     M, N, K0, K1 = 96, 80, 64, 40
     a0, a1 = _rand(M, K0, seed=3), _rand(M, K1, seed=4)

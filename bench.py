@@ -172,7 +172,7 @@ def main():
     kinds = [reps[0][i][0] for i in range(n_l)]
     flops = [reps[0][i][2] for i in range(n_l)]
     if args.dump_launches and rank == 0:
-        names = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "dropout", "ce", "ln_reduce"]
+        names = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "dropout", "ce", "ln_reduce", "cast_bf16"]
         with open(args.dump_launches, "w") as f:
             for i in range(n_l):
                 tf = flops[i] / (avg_ms[i] * 1e-3) / 1e12 if avg_ms[i] > 0 else 0.0

@@ -41,15 +41,15 @@ enum { M2F_F32 = 0, M2F_BF16 = 1 };    /* GEMM operand precision: exact-fp32 MFM
 
 /* Buffers inside the caller-provided workspace that the host reads / writes (m2f_plan_buffer). */
 enum {
-    M2F_BUF_TEXT = 0,       /* float [B*L, d_text]   input  (batch["text"],  src/train.py:222)          */
-    M2F_BUF_AUDIO = 1,      /* float [B*L, d_audio]  input  (batch["audio"], src/train.py:223)          */
+    M2F_BUF_TEXT = 0,       /* float [B*L, pad8(d_text)]  input (batch["text"], src/train.py:222); rows padded to x8  */
+    M2F_BUF_AUDIO = 1,      /* float [B*L, pad8(d_audio)] input (batch["audio"], src/train.py:223); pad columns stay 0 */
     M2F_BUF_KEYPAD = 2,     /* uint8 [B*L]           input  (batch["padding_mask"], 1 = pad, :225)      */
     M2F_BUF_LABELS = 3,     /* int64 [B*L]           input  (batch["emotion"], -1 = ignore, :224)       */
     M2F_BUF_CLASSW = 4,     /* float [16]            input  optional class weights (src/train.py:45-48) */
     M2F_BUF_LOGITS = 5,     /* float [B*L, cls_out]  output (M2FNet.forward, src/model.py:145)          */
     M2F_BUF_LOSS = 6,       /* float [4]: loss, denominator, numerator, - ; for train plans this IS grads[total..] */
     M2F_BUF_DLOGITS = 7,    /* float [B*L, cls_out]  d loss / d logits (written by m2f_loss, or by host) */
-    M2F_BUF_FAM0_OUT = 8,   /* float [B*L, d_fam]    first fusion layer output (kernel-level parity)     */
+    M2F_BUF_FAM0_OUT = 8,   /* float [B*L, pad8(d_fam)] first fusion layer output (kernel-level parity)  */
     M2F_BUF_COUNT = 9
 };
 
@@ -119,8 +119,12 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1,
              const float* gate, int ldgate, float gate_scale, float* bias_grad,
              int relu_a, int relu_b, int relu_out, int accumulate,
              uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile,
-             float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles, m2f_stream_t stream);
-/* splitk_ws / splitk_tickets (nullable): scratch for in-launch split-K of launches too small to fill the chip:
+             float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles,
+             const uint16_t* a0_bf16, int lda0_bf16, const uint16_t* a1_bf16, int lda1_bf16,
+             const uint16_t* b0_bf16, int ldb0_bf16, const uint16_t* b1_bf16, int ldb1_bf16, m2f_stream_t stream);
+/* a*_bf16 / b*_bf16 (nullable): bf16 copies of the operands (same logical elements; leading dimensions multiples of 8,
+ * pad columns zero).  In bf16 mode a launch whose operands all have one stages from them (half the bytes per CU).
+ * splitk_ws / splitk_tickets (nullable): scratch for in-launch split-K of launches too small to fill the chip:
  * splitk_max_tiles * 4 * 64*64 floats and splitk_max_tiles ZEROED uint32 tickets (re-armed by the kernel). */
 /* softmax(q k^T / sqrt(hd) + key_padding_mask) v per (dialogue, head) (nn.MultiheadAttention inside
  * src/model.py:8,14,61,73); probs receives P^T per head, padded to Lp = 16*ceil(L/16). */

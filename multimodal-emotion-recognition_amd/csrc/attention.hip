@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
     uint32_t key = 0;
     if (site) key = m2f_site_key(ab.rng, site);
     float* probs = P.probs + (size_t)bh * Lp * Lp;
+    uint16_t* out16 = m2f_shadow_of(ab.sh, P.out);
 
 #pragma unroll 1
     for (int it = 0; it < NT; ++it) {
@@ -134,7 +135,11 @@ __global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int io = 16 * it + 4 * lg + r;
-                if (io < L && c < hd) P.out[(tok0 + io) * P.ldo + h * hd + c] = o[r];
+                if (io < L && c < hd) {
+                    const size_t idx = (tok0 + io) * P.ldo + h * hd + c;
+                    P.out[idx] = o[r];
+                    if (out16) out16[idx] = m2f_bf16_bits(o[r]);
+                }
             }
         }
     }
@@ -184,6 +189,9 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
     uint32_t key = 0;
     if (site) key = m2f_site_key(ab.rng, site);
     const float* probs = P.probs + (size_t)bh * Lp * Lp;
+    uint16_t* dq16 = m2f_shadow_of(ab.sh, P.dq);
+    uint16_t* dk16 = m2f_shadow_of(ab.sh, P.dk);
+    uint16_t* dv16 = m2f_shadow_of(ab.sh, P.dv);
 
     // ---- orientation X: lane = query row i, registers = keys j  ->  dQ = dS K ----------------------
 #pragma unroll 1
@@ -218,7 +226,11 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int io = 16 * it + 4 * lg + r;
-                if (io < L && c < hd) P.dq[(tok0 + io) * P.lddq + h * hd + c] = o[r];
+                if (io < L && c < hd) {
+                    const size_t idx = (tok0 + io) * P.lddq + h * hd + c;
+                    P.dq[idx] = o[r];
+                    if (dq16) dq16[idx] = m2f_bf16_bits(o[r]);
+                }
             }
         }
     }
@@ -265,8 +277,11 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
             for (int r = 0; r < 4; ++r) {
                 const int jo = 16 * jt + 4 * lg + r;
                 if (jo < L && c < hd) {
-                    P.dk[(tok0 + jo) * P.lddk + h * hd + c] = dk[r];
-                    P.dv[(tok0 + jo) * P.lddv + h * hd + c] = dv[r];
+                    const size_t ik = (tok0 + jo) * P.lddk + h * hd + c, iv = (tok0 + jo) * P.lddv + h * hd + c;
+                    P.dk[ik] = dk[r];
+                    P.dv[iv] = dv[r];
+                    if (dk16) dk16[ik] = m2f_bf16_bits(dk[r]);
+                    if (dv16) dv16[iv] = m2f_bf16_bits(dv[r]);
                 }
             }
         }

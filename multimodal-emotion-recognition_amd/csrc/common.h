@@ -44,3 +44,10 @@ __device__ __forceinline__ float m2f_wave_max(float v) {
 }
 
 static inline int m2f_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// fp32 -> bf16 bits, round to nearest even (same rounding the GEMM staging applies; NaN stays NaN)
+__device__ __forceinline__ uint16_t m2f_bf16_bits(float x) {
+    const __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float m2f_bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }

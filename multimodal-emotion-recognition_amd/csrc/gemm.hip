@@ -26,6 +26,7 @@
 //     also emits the bias gradient (column sums of dY) from the tiles it already streams.
 #include "common.h"
 #include "ops.h"
+#include <cstdlib>
 
 namespace {
 
@@ -215,6 +216,61 @@ struct Stage {
         else store_impl<false>(lds, relu, do_cs, cs);
     }
 };
+
+// Fused epilogue shared by the fp32-source and bf16-source kernels:
+//   +bias[n] -> relu -> dropout(site) -> +res[m,n] -> *(gate[m,n] > 0 ? gate_scale : 0) -> (C += | C =) [-> bf16 shadow of C]
+// Side loads are unconditional (clamped) and issued before the arithmetic; stores are predicated.
+template <int MI, int NI, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmProblem& P, f32x16 (&acc)[MI][NI], int m0, int n0,
+                                              int lane, int wm, int wn) {
+    const int M = P.M, N = P.N;
+    const uint32_t flags = P.flags;
+    const float* bias = P.bias;
+    const float* res = P.res;
+    const float* gate = P.gate;
+    float* C = P.c;
+    uint16_t* C16 = m2f_shadow_of(gb.sh, C);
+    const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
+    const float gscale = P.gate_scale;
+    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
+    const uint32_t site = P.drop_site;
+    uint32_t key = 0;
+    if (site) key = m2f_site_key(gb.rng, site);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            const bool col_ok = col < N;
+            const int colc = col_ok ? col : 0;
+            const float bv = bias ? bias[colc] : 0.f;
+            const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+            float rv[16], gv[16], cv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                const int rowc = row < M ? row : 0;
+                rv[r] = res ? res[(size_t)rowc * ldres + colc] : 0.f;
+                gv[r] = gate ? gate[(size_t)rowc * ldgate + colc] : 1.f;
+                cv[r] = accum ? C[(size_t)rowc * ldc + colc] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bv;
+                if (relu_out) v = fmaxf(v, 0.f);
+                if (site) v = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? v * gb.drop_scale : 0.f;
+                v += rv[r];
+                if (gate) v = gv[r] > 0.f ? v * gscale : 0.f;
+                v += cv[r];
+                if (row < M && col_ok) {
+                    C[(size_t)row * ldc + col] = v;
+                    if (C16) C16[(size_t)row * ldc + col] = m2f_bf16_bits(v);
+                }
+            }
+        }
+    }
+}
 
 // LDS-only workgroup barrier: wait for this wave's LDS traffic, then s_barrier.  __syncthreads() carries a
 // workgroup-scope fence for which hipcc also drains vmcnt(0), i.e. the prefetched global loads of the next
@@ -412,49 +468,319 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
                 }
     }
 
-    // ---- fused epilogue ---------------------------------------------------------------------------
-    const float* bias = P.bias;
-    const float* res = P.res;
-    const float* gate = P.gate;
-    float* C = P.c;
-    const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
-    const float gscale = P.gate_scale;
-    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
-    const uint32_t site = P.drop_site;
-    uint32_t key = 0;
-    if (site) key = m2f_site_key(gb.rng, site);
+    gemm_epilogue<MI, NI, BM, BN>(gb, P, acc, m0, n0, lane, wm, wn);
+}
+
+// =========================================================================================================
+// bf16-SOURCE kernel (bf16 mode): operands are read from the bf16 shadows (half the bytes through the per-CU load
+// pipe, which is what bounds these GEMMs), 16 bytes = 8 elements per load, no conversion, D k-tiles in flight.
+// Pad columns of every shadow are zero, so a logical width that is not a multiple of 8 needs no element masks.
+// =========================================================================================================
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+    const uint32_t m = ((v >> 15) & 0x00010001u) * 0xFFFFu;      // 0xFFFF in every half whose sign bit is set
+    return v & ~m;
+}
+__device__ __forceinline__ float bf16lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
+
+template <int BR, int BK>
+struct Stage16KC {                       // element (row, k) at q[row*ld + k]
+    static constexpr int KCH = BK / 8, NT = BR * KCH / 256;
+    static constexpr int ROWB = BK * 2 + 16, LDS_BYTES = BR * ROWB;
+    static_assert(NT >= 1 && (BR * KCH) % 256 == 0, "tile split");
+    uint4 v[NT];
+    int off[NT];
+    int ld_, rows_, row0_, kpad_, kbase_;
+    bool full_;
+    __device__ __forceinline__ void setup(int ld, int rows, int row0) {
+        ld_ = ld; rows_ = rows; row0_ = row0;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int t = 0; t < NT; ++t) {
+            const int id = threadIdx.x + 256 * t, r = id / KCH, kc = id % KCH;
+            int gr = row0 + r;
+            gr = gr < rows - 1 ? gr : rows - 1;
+            off[t] = gr * ld + 8 * kc;
+        }
+    }
+    __device__ __forceinline__ void issue(const uint16_t* __restrict__ q, int kseg, int kbase) {
+        kpad_ = (kseg + 7) & ~7; kbase_ = kbase;
+        full_ = (row0_ + BR <= rows_) && (kbase + BK <= kpad_);
+        const uint16_t* pt = q + kbase;
+        if (full_) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            const bool col_ok = col < N;
-            const int colc = col_ok ? col : 0;
-            const float bv = bias ? bias[colc] : 0.f;
-            const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
-            // all side loads first (unconditional, clamped), then the arithmetic, then predicated stores
-            float rv[16], gv[16], cv[16];
+            for (int t = 0; t < NT; ++t) v[t] = *reinterpret_cast<const uint4*>(pt + off[t]);
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + (r & 3) + 8 * (r >> 2);
-                const int rowc = row < M ? row : 0;
-                rv[r] = res ? res[(size_t)rowc * ldres + colc] : 0.f;
-                gv[r] = gate ? gate[(size_t)rowc * ldgate + colc] : 1.f;
-                cv[r] = accum ? C[(size_t)rowc * ldc + colc] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bv;
-                if (relu_out) v = fmaxf(v, 0.f);
-                if (site) v = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? v * gb.drop_scale : 0.f;
-                v += rv[r];
-                if (gate) v = gv[r] > 0.f ? v * gscale : 0.f;
-                v += cv[r];
-                if (row < M && col_ok) C[(size_t)row * ldc + col] = v;
+            for (int t = 0; t < NT; ++t) {
+                const int kc = (threadIdx.x + 256 * t) % KCH;
+                const int o = (kbase + 8 * kc < kpad_) ? off[t] : off[t] - 8 * kc - kbase;     // else: row start
+                v[t] = *reinterpret_cast<const uint4*>(pt + o);
             }
         }
     }
+    __device__ __forceinline__ void store(char* lds, bool relu) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int id = threadIdx.x + 256 * t, r = id / KCH, kc = id % KCH;
+            uint4 x = v[t];
+            if (!full_) {
+                const bool ok = (row0_ + r < rows_) && (kbase_ + 8 * kc < kpad_);
+                if (!ok) x = make_uint4(0u, 0u, 0u, 0u);
+            }
+            if (relu) { x.x = relu_bf16x2(x.x); x.y = relu_bf16x2(x.y); x.z = relu_bf16x2(x.z); x.w = relu_bf16x2(x.w); }
+            *reinterpret_cast<uint4*>(lds + r * ROWB + kc * 16) = x;
+        }
+    }
+};
+
+template <int BR, int BK>
+struct Stage16RC {   // element (row, k) at q[k*ld + row]; one 8(k) x 8(row) patch per active thread
+    // LDS image is K-MAJOR: [k][row] bf16 with row stride ROWK = 2*BR + 64 bytes, written exactly as loaded (16-byte
+    // vectors, lanes = consecutive row groups -> conflict-free) and consumed with ds_read_b64_tr_b16, the gfx950
+    // transposing LDS read (4 k-rows x 16 rows per 16-lane group; with this stride the 4 k-rows of a group fall on
+    // disjoint bank ranges).  No register transposes, no scattered stores.
+    static constexpr int KP = BK / 8, RP = BR / 8, NPATCH = KP * RP;
+    static constexpr int ROWK = 2 * BR + 16, LDS_BYTES = BK * ROWK;   // +16: 2-way conflicts on the tr reads, but 2 workgroups fit a CU
+    static_assert(NPATCH == 128, "one patch per thread of a 128-thread half");
+    uint4 v[8];
+    int off, kp_, rp_;
+    int ld_, rows_, row0_, kseg_, kbase_;
+    bool full_, active_;
+    __device__ __forceinline__ void setup(int ld, int rows, int row0, int pid) {
+        ld_ = ld; rows_ = rows; row0_ = row0;
+        active_ = pid >= 0 && pid < NPATCH;
+        const int p = active_ ? pid : 0;
+        kp_ = p / RP; rp_ = p % RP;
+        const int rpad = (rows + 7) & ~7;
+        int gr = row0 + 8 * rp_;
+        gr = gr < rpad - 8 ? gr : rpad - 8;
+        off = 8 * kp_ * ld + (gr > 0 ? gr : 0);
+    }
+    __device__ __forceinline__ void issue(const uint16_t* __restrict__ q, int kseg, int kbase) {
+        kseg_ = kseg; kbase_ = kbase;
+        full_ = (row0_ + BR <= rows_) && (kbase + BK <= kseg);
+        if (!active_) return;                                   // wave-uniform (patches are dealt per 128-thread half)
+        const uint16_t* pt = q + (size_t)kbase * ld_;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int o = off + j * ld_;
+            if (!full_) o = (kbase + 8 * kp_ + j < kseg) ? o : off - 8 * kp_ * ld_ - kbase * ld_;   // else: k = 0 row
+            v[j] = *reinterpret_cast<const uint4*>(pt + o);
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, bool relu, bool do_cs, float (&cs)[8]) {
+        if (!active_) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            if (!full_) {
+                const bool kok = kbase_ + 8 * kp_ + j < kseg_;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int r = row0_ + 8 * rp_ + 2 * m;
+                    uint32_t keep = 0u;
+                    if (kok && r < rows_) keep |= 0x0000FFFFu;
+                    if (kok && r + 1 < rows_) keep |= 0xFFFF0000u;
+                    w[m] &= keep;
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) w[m] = relu_bf16x2(w[m]);
+            }
+            if (do_cs) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { cs[2 * m] += bf16lo(w[m]); cs[2 * m + 1] += bf16hi(w[m]); }
+            }
+            *reinterpret_cast<uint4*>(lds + (8 * kp_ + j) * ROWK + 16 * rp_) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+};
+
+typedef short m2f_s16x4 __attribute__((ext_vector_type(4)));
+// MFMA 32x32x16 operand fragment (8 consecutive k of row `row`) out of a K-major LDS image via two transposing reads.
+// Per 16-lane group g: lane 4q+p supplies the address of k-row (4t + q), rows 4p..4p+3; lane i receives row i.
+__device__ __forceinline__ bf16x8 frag_from_kmajor(const char* img, int rowk, int row_base32, int k0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int kq = k0 + 8 * (g >> 1) + q;                       // + 4t
+    const int col = row_base32 + 16 * (g & 1) + 4 * p;
+    const char* a0 = img + kq * rowk + col * 2;
+    const m2f_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (m2f_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a0)));
+    const m2f_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (m2f_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a0 + 4 * rowk)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
+    static_assert(!(A_RC && !B_RC), "layouts: NT, NN, TN");
+    constexpr bool TN = A_RC && B_RC;
+    static_assert(!TN || BM == BN, "the TN stager shares one patch shape for both operands");
+    using SAK = Stage16KC<BM, BK>;
+    using SBK = Stage16KC<BN, BK>;
+    using SBR = Stage16RC<BN, BK>;
+    constexpr int ROWB = SAK::ROWB, ROWK = SBR::ROWK;
+    constexpr int LDS_A = A_RC ? Stage16RC<BM, BK>::LDS_BYTES : SAK::LDS_BYTES;
+    constexpr int LDS_B = B_RC ? SBR::LDS_BYTES : SBK::LDS_BYTES;
+    constexpr int MI = BM / 64, NI = BN / 64;
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;                 // unroll so that set and LDS-buffer indices are static
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < M2F_GEMM_MAX_PROBLEMS; ++i)
+        if (i < gb.count && (int)blockIdx.x >= gb.pr[i].tile_begin) pi = i;
+    const GemmProblem& P = gb.pr[pi];
+    const int M = P.M, N = P.N;
+    const int tl = (int)blockIdx.x - P.tile_begin;
+    const int m0 = (tl / P.tiles_n) * BM, n0 = (tl % P.tiles_n) * BN;
+    const uint32_t flags = P.flags;
+    const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
+    const int nk0 = (P.a.k[0] + BK - 1) / BK, nk = nk0 + (P.a.k[1] + BK - 1) / BK;
+    char* ldsA = smem;
+    char* ldsB = smem + 2 * LDS_A;
+
+    // one register set = this thread's share of one k-tile of both operands
+    struct Set {
+        SAK ak;            // NT, NN: A
+        SBK bk;            // NT: B
+        SBR br;            // NN: B (threads 0..127) | TN: A (threads 0..127) or B (threads 128..255)
+    };
+    Set sets[D];
+    int cur_seg = -1;
+    const bool second_half = tid >= 128;
+    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool want_bg = TN && P.bias_grad != nullptr && n0 == 0 && !second_half;
+
+    auto setup_all = [&](int seg) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if constexpr (!A_RC) sets[i].ak.setup(P.a.ldq[seg], M, m0);
+            if constexpr (!B_RC) sets[i].bk.setup(P.b.ldq[seg], N, n0);
+            if constexpr (!A_RC && B_RC) sets[i].br.setup(P.b.ldq[seg], N, n0, tid);
+            if constexpr (TN) {
+                if (second_half) sets[i].br.setup(P.b.ldq[seg], N, n0, tid - 128);
+                else sets[i].br.setup(P.a.ldq[seg], M, m0, tid);
+            }
+        }
+    };
+    auto issue = [&](Set& st, int kt_raw) {                     // unconditional: past-the-end tiles are fully masked
+        const bool tv = kt_raw < nk;
+        const int kt = tv ? kt_raw : 0;
+        const int seg = kt >= nk0 ? 1 : 0;
+        const int kbase = (seg ? kt - nk0 : kt) * BK;
+        if (seg != cur_seg) { setup_all(seg); cur_seg = seg; }   // wave-uniform, at most twice
+        const int ks = tv ? P.a.k[seg] : 0;
+        if constexpr (!A_RC) st.ak.issue(P.a.q[seg], ks, kbase);
+        if constexpr (!B_RC) st.bk.issue(P.b.q[seg], ks, kbase);
+        if constexpr (!A_RC && B_RC) st.br.issue(P.b.q[seg], ks, kbase);
+        if constexpr (TN) st.br.issue(second_half ? P.b.q[seg] : P.a.q[seg], ks, kbase);
+    };
+    auto store = [&](Set& st, int buf) {
+        if constexpr (!A_RC) st.ak.store(ldsA + buf * LDS_A, reluA);
+        if constexpr (!B_RC) st.bk.store(ldsB + buf * LDS_B, reluB);
+        if constexpr (!A_RC && B_RC) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
+        if constexpr (TN) {
+            if (second_half) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
+            else st.br.store(ldsA + buf * LDS_A, reluA, want_bg, colsum);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char* aimg = ldsA + buf * LDS_A;
+        const char* bimg = ldsB + buf * LDS_B;
+        const char* ab = aimg + (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;      // row-major images
+        const char* bb = bimg + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (A_RC) a[i] = frag_from_kmajor(aimg, ROWK, wm * (BM / 2) + i * 32, 16 * ks, lane);
+                else a[i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (B_RC) b[j] = frag_from_kmajor(bimg, ROWK, wn * (BN / 2) + j * 32, 16 * ks, lane);
+                else b[j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < D; ++i) issue(sets[i], i);
+    store(sets[0], 0);
+    lds_barrier();
+    issue(sets[0], D);
+
+    for (int kt0 = 0; kt0 < nk; kt0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u;
+            if (kt < nk) {                                       // block-uniform
+                compute(u & 1);
+                store(sets[(u + 1) % D], (u + 1) & 1);           // tile kt+1 (all-zero past the end)
+                lds_barrier();
+                issue(sets[(u + 1) % D], kt + 1 + D);
+            }
+        }
+    }
+
+    if constexpr (TN) {
+        if (P.bias_grad != nullptr && n0 == 0) {                 // block-uniform
+            // threads 0..127 hold column sums of their 8 rows over their k-group: red[kp][row], then fixed-order sum
+            float* red = reinterpret_cast<float*>(smem);
+            constexpr int KP = BK / 8, RP = BM / 8;
+            if (!second_half) {
+                const int kp = tid / RP, rp = tid % RP;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[kp * BM + 8 * rp + e] = colsum[e];
+            }
+            __syncthreads();
+            if (tid < BM) {
+                float sum = 0.f;
+                for (int q = 0; q < KP; ++q) sum += red[q * BM + tid];
+                if (m0 + tid < M) P.bias_grad[m0 + tid] = sum;
+            }
+        }
+    }
+    gemm_epilogue<MI, NI, BM, BN>(gb, P, acc, m0, n0, lane, wm, wn);
+}
+
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
+    constexpr int lds = 2 * (A_RC ? Stage16RC<BM, BK>::LDS_BYTES : Stage16KC<BM, BK>::LDS_BYTES) +
+                        2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(256), lds, stream, gb);
+    return hipGetLastError();
 }
 
 template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC>
@@ -534,6 +860,48 @@ hipError_t launch_tile(GemmBatch& gb, int tile, hipStream_t stream) {
                : launch_cfg<PREC, A_RC, B_RC, 64, 64, BK64, false>(gb, t, stream);
 }
 
+template <bool A_RC, bool B_RC>
+hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
+    auto count_tiles = [&](int bm, int bn) {
+        int t = 0;
+        for (int i = 0; i < gb.count; ++i) t += m2f_cdiv(gb.pr[i].M, bm) * m2f_cdiv(gb.pr[i].N, bn);
+        return t;
+    };
+    if (tile == 0) tile = (count_tiles(128, 128) >= 512) ? 128 : 64;
+    int t = 0;
+    for (int i = 0; i < gb.count; ++i) {
+        GemmProblem& p = gb.pr[i];
+        p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0;
+        p.tile_begin = t;
+        p.tiles_n = m2f_cdiv(p.N, tile);
+        t += m2f_cdiv(p.M, tile) * p.tiles_n;
+    }
+    if (t == 0) return hipSuccess;
+    constexpr int D64 = (!A_RC && B_RC) ? 3 : 4;     // dgrad holds a 32-register patch per set -> one stage less
+    if (tile == 128) return launch_cfg16<A_RC, B_RC, 128, 128, 64, 3>(gb, t, stream);
+    // (a 6-deep variant that keeps the whole K = 768 in flight was measured: no gain over 4)
+    return launch_cfg16<A_RC, B_RC, 64, 64, 128, D64>(gb, t, stream);
+}
+
+// can every operand of every problem be staged from its bf16 shadow with 16-byte loads?
+bool src16_ok(const GemmBatch& gb, bool a_rc, bool b_rc) {
+    auto seg_ok = [](const GemmOperand& o, bool rc, int rows) {
+        for (int s = 0; s < 2; ++s) {
+            if (o.k[s] == 0) continue;
+            if (!o.q[s] || (reinterpret_cast<uintptr_t>(o.q[s]) & 15) || (o.ldq[s] & 7)) return false;
+            const int extent = rc ? rows : o.k[s];           // the contiguous dimension
+            if ((extent & 7) && o.ldq[s] != ((extent + 7) & ~7)) return false;   // pads must be the buffer's own zero pads
+            if (o.ldq[s] < extent) return false;
+        }
+        return true;
+    };
+    for (int i = 0; i < gb.count; ++i) {
+        const GemmProblem& p = gb.pr[i];
+        if (!seg_ok(p.a, a_rc, p.M) || !seg_ok(p.b, b_rc, p.N)) return false;
+    }
+    return true;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool vec_ok(const GemmOperand& o, bool rc, int rows) {
@@ -560,6 +928,25 @@ hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStr
         p.flags &= ~(uint32_t)(GF_VEC_A | GF_VEC_B);
         if (vec_ok(p.a, a_rc, p.M)) p.flags |= GF_VEC_A;
         if (vec_ok(p.b, b_rc, p.N)) p.flags |= GF_VEC_B;
+    }
+    if (prec == M2F_PREC_BF16 && layout == M2F_LAYOUT_NN) {
+        // dgrad against a weight whose TRANSPOSED bf16 shadow exists runs as the k-contiguous (forward) form, the
+        // fastest staging path: C = A * B  ==  A * (B^T)^T
+        bool all_t = true;
+        for (int i = 0; i < gb.count; ++i)
+            for (int sgm = 0; sgm < 2; ++sgm)
+                if (gb.pr[i].b.k[sgm] && !gb.pr[i].b.qt[sgm]) all_t = false;
+        if (all_t) {
+            GemmBatch t = gb;
+            for (int i = 0; i < t.count; ++i)
+                for (int sgm = 0; sgm < 2; ++sgm) { t.pr[i].b.q[sgm] = t.pr[i].b.qt[sgm]; t.pr[i].b.ldq[sgm] = t.pr[i].b.ldqt[sgm]; }
+            if (src16_ok(t, false, false)) return launch_tile16<false, false>(t, tile, stream);
+        }
+    }
+    if (prec == M2F_PREC_BF16 && src16_ok(gb, a_rc, b_rc)) {
+        if (layout == M2F_LAYOUT_NT) return launch_tile16<false, false>(gb, tile, stream);
+        if (layout == M2F_LAYOUT_NN) return launch_tile16<false, true>(gb, tile, stream);
+        return launch_tile16<true, true>(gb, tile, stream);
     }
     if (prec == M2F_PREC_F32) {
         if (layout == M2F_LAYOUT_NT) return launch_tile<M2F_PREC_F32, false, false>(gb, tile, stream);

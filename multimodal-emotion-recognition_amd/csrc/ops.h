@@ -26,6 +26,23 @@ struct GemmOperand {
     const float* p[2];
     int ld[2];
     int k[2];          // reduction length of each segment (k[1] == 0: single segment)
+    // bf16 shadow of the same data (bf16 mode): same logical element (row, k), own leading dimension; the columns
+    // between the logical width and ldq are zero.  null = no shadow (the launch then stages from fp32).
+    const uint16_t* q[2];
+    int ldq[2];
+    // B operand of the dgrad form only: bf16 shadow of the TRANSPOSED matrix (element (row, k) at qt[row*ldqt + k]),
+    // which lets the launch run as the k-contiguous (forward) form.  null = not available.
+    const uint16_t* qt[2];
+    int ldqt[2];
+};
+
+// bf16 shadows of workspace activations: element i of the fp32 workspace has its shadow at shadow[i] (activation
+// buffers use leading dimensions that are multiples of 8, so shadows keep 16-byte row alignment).  Producer kernels
+// write both copies; ws_base == null disables shadow writes.
+struct ShadowMap {
+    const float* ws_base;
+    uint16_t* shadow;
+    size_t ws_floats;
 };
 
 struct GemmProblem {
@@ -55,6 +72,7 @@ struct GemmBatch {
     float* splitk_ws;
     unsigned* splitk_cnt;
     int splitk_max_tiles;
+    ShadowMap sh;             // C (when it lies in the workspace) is also written as bf16
 };
 #define M2F_SPLITK_MAX_TILES 512
 
@@ -86,6 +104,7 @@ struct AttnBatch {
     const uint32_t* rng;
     uint32_t drop_thresh;
     float drop_scale;
+    ShadowMap sh;              // out (fwd) / dq, dk, dv (bwd) also written as bf16
 };
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
 hipError_t m2f_launch_attn_bwd(AttnBatch& ab, hipStream_t stream);
@@ -99,6 +118,7 @@ struct LnProblem {
     const float* x; const float* gamma; const float* beta; const float* res;
     float* out; float* stats;          // stats [T, 2] = (mean, rstd)
     int d;
+    int ld;                            // row stride of x / res / out / dy / extra / dx / dx_masked (0 = d)
     uint32_t drop_site;
     // backward: dx = LNbwd(dy) (+ extra) ; optional second output dx_masked = LNbwd(dy) * keep(site2)/(1-p)
     const float* dy; const float* extra;
@@ -114,6 +134,7 @@ struct LnBatch {
     int T;
     float eps;
     const uint32_t* rng; uint32_t drop_thresh; float drop_scale;
+    ShadowMap sh;                      // out (fwd) / dx, dx_masked (bwd) also written as bf16
 };
 #define M2F_LN_ROWS_PER_BLOCK 4
 hipError_t m2f_launch_ln_fwd(LnBatch& lb, hipStream_t stream);
@@ -144,9 +165,16 @@ hipError_t m2f_launch_ce(const CeArgs& a, hipStream_t stream);
 hipError_t m2f_launch_loss_finalize(const float* loss_terms, int T, int C, float* dlogits, float* loss_out,
                                     int normalise, hipStream_t stream);
 
+// fp32 -> bf16 (round to nearest even) of up to M2F_CAST_MAX_ITEMS 2-D blocks in one launch: dst[r*ldd + c] =
+// bf16(src[r*lds + c]) for c < cols (pad columns of dst are left untouched = zero).
+struct CastItem { const float* src; uint16_t* dst; int rows, cols, lds, ldd; uint16_t* dst_t; int ldd_t; };   // dst_t: transposed copy [cols][rows] (nullable)
+#define M2F_CAST_MAX_ITEMS 48
+struct CastBatch { CastItem it[M2F_CAST_MAX_ITEMS]; int count; };
+hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream);
+
 // in-place: x[t, c] *= keep(site, t*d + c) / (1 - p)
 hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
-                                      uint32_t thresh, float scale, hipStream_t stream);
+                                      uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream);
 // rng.step += 1 (device side, graph-replay safe)
 hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream);
 
@@ -156,3 +184,12 @@ hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream);
 hipError_t m2f_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
                            hipStream_t stream);
+
+#ifdef __HIPCC__
+// shadow address of a workspace element, or null (no shadows / pointer outside the workspace, e.g. the gradient buffer)
+__device__ __forceinline__ uint16_t* m2f_shadow_of(const ShadowMap& sh, const float* p) {
+    if (!sh.ws_base) return nullptr;
+    const ptrdiff_t i = p - sh.ws_base;
+    return (i >= 0 && (size_t)i < sh.ws_floats) ? sh.shadow + i : nullptr;
+}
+#endif

@@ -47,13 +47,22 @@ struct ParamMap {
     std::vector<LinP> cls;               // Linear0, extra hidden..., last
     std::vector<int64_t> offsets, numels;
     size_t total = 0;
+    struct Mat { size_t off; int rows, cols; size_t soff, soff_t; };   // 2-D tensors + offsets of their padded bf16 shadow
+    std::vector<Mat> mats;                                             // and of the shadow of their transpose
+    size_t shadow_elems = 0;
 };
 
-size_t pm_add(ParamMap& pm, size_t n) {
+size_t pm_add(ParamMap& pm, size_t n, int rows = 0, int cols = 0) {
     const size_t off = pm.total;
     pm.offsets.push_back((int64_t)off);
     pm.numels.push_back((int64_t)n);
     pm.total = (off + n + 63) / 64 * 64;
+    if (rows > 0 && cols > 0) {
+        const size_t so = pm.shadow_elems;
+        pm.shadow_elems += ((size_t)rows * ((cols + 7) & ~7) + 63) / 64 * 64;
+        pm.mats.push_back({off, rows, cols, so, pm.shadow_elems});
+        pm.shadow_elems += ((size_t)cols * ((rows + 7) & ~7) + 63) / 64 * 64;
+    }
     return off;
 }
 
@@ -62,13 +71,13 @@ void pm_modality(ParamMap& pm, ModalityP& m, int d, int ntrans, int nlayers, int
     for (int e = 0; e < ntrans; ++e) {
         for (int l = 0; l < nlayers; ++l) {
             EncLayerP p;
-            p.in_w = pm_add(pm, (size_t)3 * d * d);
+            p.in_w = pm_add(pm, (size_t)3 * d * d, 3 * d, d);
             p.in_b = pm_add(pm, (size_t)3 * d);
-            p.out_w = pm_add(pm, (size_t)d * d);
+            p.out_w = pm_add(pm, (size_t)d * d, d, d);
             p.out_b = pm_add(pm, d);
-            p.l1_w = pm_add(pm, (size_t)dff * d);
+            p.l1_w = pm_add(pm, (size_t)dff * d, dff, d);
             p.l1_b = pm_add(pm, dff);
-            p.l2_w = pm_add(pm, (size_t)d * dff);
+            p.l2_w = pm_add(pm, (size_t)d * dff, d, dff);
             p.l2_b = pm_add(pm, d);
             p.n1_w = pm_add(pm, d);
             p.n1_b = pm_add(pm, d);
@@ -81,7 +90,7 @@ void pm_modality(ParamMap& pm, ModalityP& m, int d, int ntrans, int nlayers, int
             m.norm_b = pm_add(pm, d);
         }
     }
-    m.proj_w = pm_add(pm, (size_t)dfam * d);
+    m.proj_w = pm_add(pm, (size_t)dfam * d, dfam, d);
     m.proj_b = pm_add(pm, dfam);
 }
 
@@ -110,28 +119,28 @@ int build_param_map(const m2f_config& c, ParamMap& pm) {
         const size_t E = c.d_fam;
         for (int i = 0; i < c.nlayers_fam; ++i) {
             FamP f;
-            f.in_w = pm_add(pm, 3 * E * E);
+            f.in_w = pm_add(pm, 3 * E * E, (int)(3 * E), (int)E);
             f.in_b = pm_add(pm, 3 * E);
-            f.out_w = pm_add(pm, E * E);
+            f.out_w = pm_add(pm, E * E, (int)E, (int)E);
             f.out_b = pm_add(pm, E);
-            f.lin_w = pm_add(pm, E * 2 * E);
+            f.lin_w = pm_add(pm, E * 2 * E, (int)E, (int)(2 * E));
             f.lin_b = pm_add(pm, E);
             pm.fam.push_back(f);
         }
     }
     const size_t h = c.cls_hidden, in = cls_in_width(c);
     LinP l0;
-    l0.w = pm_add(pm, h * in);
+    l0.w = pm_add(pm, h * in, (int)h, (int)in);
     l0.b = pm_add(pm, h);
     pm.cls.push_back(l0);
     for (int j = 0; j < std::max(c.cls_layers - 2, 0); ++j) {
         LinP l;
-        l.w = pm_add(pm, h * h);
+        l.w = pm_add(pm, h * h, (int)h, (int)h);
         l.b = pm_add(pm, h);
         pm.cls.push_back(l);
     }
     LinP ll;
-    ll.w = pm_add(pm, (size_t)c.cls_out * h);
+    ll.w = pm_add(pm, (size_t)c.cls_out * h, c.cls_out, (int)h);
     ll.b = pm_add(pm, c.cls_out);
     pm.cls.push_back(ll);
     return 0;
@@ -216,6 +225,10 @@ struct m2f_plan {
     ParamMap pm;
     void* bufs[M2F_BUF_COUNT] = {nullptr};
     float* loss_terms = nullptr;
+    // bf16 mode: shadows of the workspace activations (same element index) and of the 2-D parameters (padded rows)
+    ShadowMap sh = {nullptr, nullptr, 0};
+    uint16_t* wshadow = nullptr;
+    std::vector<CastBatch> casts;        // parameters + input staging -> bf16, at the start of every forward
     std::vector<Launch> fwd, bwd;
     // deferred weight-gradient launches run on a second stream, each as soon as the chain launch that produces its last
     // operand has been issued (wg_dep = index into bwd, -1 = operands come from the forward pass / criterion)
@@ -258,26 +271,27 @@ struct Builder {
 
     explicit Builder(m2f_plan& p) : P(p), T(p.T) {}
 
+    static int pad8(int w) { return (w + 7) & ~7; }     // activation leading dimensions: multiples of 8 (bf16 shadows stay 16-byte aligned)
     uint32_t site() { return P.use_dropout ? next_site++ : 0u; }
     const float* W(size_t off) const { return P.params + off; }
     float* G(size_t off) const { return P.grads ? P.grads + off : nullptr; }
     float gscale() const { return P.use_dropout ? P.drop_scale : 1.f; }
 
-    Op op_ln_fwd(const float* x, size_t gw, size_t gb, const float* res, float* out, float* stats, int d, uint32_t s) {
+    Op op_ln_fwd(const float* x, size_t gw, size_t gb, const float* res, float* out, float* stats, int d, int ld, uint32_t s) {
         Op o; o.kind = OP_LN_FWD;
         LnProblem p; memset(&p, 0, sizeof(p));
-        p.x = x; p.gamma = W(gw); p.beta = W(gb); p.res = res; p.out = out; p.stats = stats; p.d = d; p.drop_site = s;
+        p.x = x; p.gamma = W(gw); p.beta = W(gb); p.res = res; p.out = out; p.stats = stats; p.d = d; p.ld = ld; p.drop_site = s;
         o.lp.push_back(p);
         return o;
     }
     // shared_partial != null: the LayerNorm object is shared (final encoder norm): the caller owns one partial
     // buffer for all its uses and registers a single reduce item covering every slice.
     Op op_ln_bwd(const float* x, size_t gw, size_t gb, const float* stats, const float* dy, const float* extra,
-                 float* dx, float* dx_masked, int d, uint32_t s2, float* shared_partial = nullptr) {
+                 float* dx, float* dx_masked, int d, int ld, uint32_t s2, float* shared_partial = nullptr) {
         Op o; o.kind = OP_LN_BWD;
         LnProblem p; memset(&p, 0, sizeof(p));
         p.x = x; p.gamma = W(gw); p.stats = const_cast<float*>(stats); p.dy = dy; p.extra = extra; p.dx = dx;
-        p.dx_masked = dx_masked; p.d = d; p.drop_site2 = s2;
+        p.dx_masked = dx_masked; p.d = d; p.ld = ld; p.drop_site2 = s2;
         const int nblk = m2f_ln_row_blocks(T);
         p.partial = shared_partial ? shared_partial : ar.f((size_t)nblk * 2 * d);
         o.lp.push_back(p);
@@ -303,6 +317,7 @@ struct Builder {
         ModBuf& m = mod[bi];
         m.d = d; m.H = H; m.nl = nl; m.nt = nt; m.x_in = x_in;
         const int F = P.cfg.dim_ff, E = P.cfg.d_fam;
+        const int dp = pad8(d), d3p = pad8(3 * d), Fp = pad8(F), Ep = pad8(E);   // activation leading dimensions
         std::vector<Op>& f = br_f[bi];
         const float* x = x_in;
         m.L.resize(nt);
@@ -312,63 +327,63 @@ struct Builder {
                 const EncLayerP& p = mp.enc[e][l];
                 EncLayerBuf b;
                 b.y_in = y;
-                b.qkv = ar.f((size_t)T * 3 * d);
+                b.qkv = ar.f((size_t)T * d3p);
                 b.probs = ar.f(m2f_attn_probs_elems(P.B, H, P.L));
-                b.att = ar.f((size_t)T * d);
-                b.s1 = ar.f((size_t)T * d);
+                b.att = ar.f((size_t)T * dp);
+                b.s1 = ar.f((size_t)T * dp);
                 b.st1 = ar.f((size_t)T * 2);
-                b.y1 = ar.f((size_t)T * d);
-                b.h = ar.f((size_t)T * F);
-                b.s2 = ar.f((size_t)T * d);
+                b.y1 = ar.f((size_t)T * dp);
+                b.h = ar.f((size_t)T * Fp);
+                b.s2 = ar.f((size_t)T * dp);
                 b.st2 = ar.f((size_t)T * 2);
-                b.y2 = ar.f((size_t)T * d);
+                b.y2 = ar.f((size_t)T * dp);
                 b.site_attn = site(); b.site_d1 = site(); b.site_ff = site(); b.site_d2 = site();
                 {   // packed QKV in-projection
-                    GemmProblem g = gp_make(y, d, W(p.in_w), d, T, 3 * d, d, b.qkv, 3 * d);
+                    GemmProblem g = gp_make(y, dp, W(p.in_w), d, T, 3 * d, d, b.qkv, d3p);
                     g.bias = W(p.in_b);
                     f.push_back(op_gemm(M2F_LAYOUT_NT, g));
                 }
                 {
                     Op o; o.kind = OP_ATTN_FWD;
                     AttnProblem a; memset(&a, 0, sizeof(a));
-                    a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
-                    a.out = b.att; a.ldo = d; a.probs = b.probs; a.H = H; a.hd = d / H; a.drop_site = b.site_attn;
+                    a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = d3p;
+                    a.out = b.att; a.ldo = dp; a.probs = b.probs; a.H = H; a.hd = d / H; a.drop_site = b.site_attn;
                     o.ap.push_back(a);
                     f.push_back(o);
                 }
                 {   // out-proj -> dropout1 -> + residual
-                    GemmProblem g = gp_make(b.att, d, W(p.out_w), d, T, d, d, b.s1, d);
-                    g.bias = W(p.out_b); g.drop_site = b.site_d1; g.res = y; g.ldres = d;
+                    GemmProblem g = gp_make(b.att, dp, W(p.out_w), d, T, d, d, b.s1, dp);
+                    g.bias = W(p.out_b); g.drop_site = b.site_d1; g.res = y; g.ldres = dp;
                     f.push_back(op_gemm(M2F_LAYOUT_NT, g));
                 }
-                f.push_back(op_ln_fwd(b.s1, p.n1_w, p.n1_b, nullptr, b.y1, b.st1, d, 0));
+                f.push_back(op_ln_fwd(b.s1, p.n1_w, p.n1_b, nullptr, b.y1, b.st1, d, dp, 0));
                 {   // linear1 -> relu -> dropout
-                    GemmProblem g = gp_make(b.y1, d, W(p.l1_w), d, T, F, d, b.h, F);
+                    GemmProblem g = gp_make(b.y1, dp, W(p.l1_w), d, T, F, d, b.h, Fp);
                     g.bias = W(p.l1_b); g.flags |= GF_RELU_OUT; g.drop_site = b.site_ff;
                     f.push_back(op_gemm(M2F_LAYOUT_NT, g));
                 }
                 {   // linear2 -> dropout2 -> + residual
-                    GemmProblem g = gp_make(b.h, F, W(p.l2_w), F, T, d, F, b.s2, d);
-                    g.bias = W(p.l2_b); g.drop_site = b.site_d2; g.res = b.y1; g.ldres = d;
+                    GemmProblem g = gp_make(b.h, Fp, W(p.l2_w), F, T, d, F, b.s2, dp);
+                    g.bias = W(p.l2_b); g.drop_site = b.site_d2; g.res = b.y1; g.ldres = dp;
                     f.push_back(op_gemm(M2F_LAYOUT_NT, g));
                 }
-                f.push_back(op_ln_fwd(b.s2, p.n2_w, p.n2_b, nullptr, b.y2, b.st2, d, 0));
+                f.push_back(op_ln_fwd(b.s2, p.n2_w, p.n2_b, nullptr, b.y2, b.st2, d, dp, 0));
                 y = b.y2;
                 m.L[e].push_back(b);
             }
             // x_e = x_{e-1} + LNf(y); the last one feeds `dropout -> proj` (src/model.py:111,123)
-            float* xe = ar.f((size_t)T * d);
+            float* xe = ar.f((size_t)T * dp);
             float* stf = ar.f((size_t)T * 2);
             const uint32_t s = (e == nt - 1) ? (m.site_pre = site()) : 0u;
-            f.push_back(op_ln_fwd(y, mp.norm_w, mp.norm_b, x, xe, stf, d, s));
+            f.push_back(op_ln_fwd(y, mp.norm_w, mp.norm_b, x, xe, stf, d, dp, s));
             m.xe.push_back(xe);
             m.stf.push_back(stf);
             x = xe;
         }
-        m.xp = ar.f((size_t)T * E);
+        m.xp = ar.f((size_t)T * Ep);
         m.site_post = site();
         {
-            GemmProblem g = gp_make(x, d, W(mp.proj_w), d, T, E, d, m.xp, E);
+            GemmProblem g = gp_make(x, dp, W(mp.proj_w), d, T, E, d, m.xp, Ep);
             g.bias = W(mp.proj_b); g.drop_site = m.site_post;
             f.push_back(op_gemm(M2F_LAYOUT_NT, g));
         }
@@ -378,18 +393,19 @@ struct Builder {
     void build_modality_bwd(int bi, const ModalityP& mp, const float* dxp) {
         ModBuf& m = mod[bi];
         const int d = m.d, H = m.H, nl = m.nl, nt = m.nt, F = P.cfg.dim_ff, E = P.cfg.d_fam;
+        const int dp = pad8(d), d3p = pad8(3 * d), Fp = pad8(F), Ep = pad8(E);
         std::vector<Op>& bw = br_b[bi];
         const int saved_chain = cur_chain;
         {   // the projection wgrad reads d(xp), produced by the head chain (everything emitted so far)
             cur_chain = 2;
         }
         const float* x_last = nt > 0 ? m.xe[nt - 1] : m.x_in;
-        wgrad(dxp, E, x_last, d, E, d, mp.proj_w, d, (long)mp.proj_b);
+        wgrad(dxp, Ep, x_last, dp, E, d, mp.proj_w, d, (long)mp.proj_b);
         cur_chain = bi;
         if (nt == 0) { cur_chain = saved_chain; return; }
-        float* dx = ar.f((size_t)T * d);
+        float* dx = ar.f((size_t)T * dp);
         {
-            GemmProblem g = gp_make(dxp, E, W(mp.proj_w), d, T, d, E, dx, d);
+            GemmProblem g = gp_make(dxp, Ep, W(mp.proj_w), d, T, d, E, dx, dp);
             g.drop_site = m.site_pre;
             bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
         }
@@ -402,8 +418,8 @@ struct Builder {
         }
         for (int e = nt - 1; e >= 0; --e) {
             const float* yN = nl > 0 ? m.L[e][nl - 1].y2 : (e > 0 ? m.xe[e - 1] : m.x_in);
-            float* g_cur = ar.f((size_t)T * d);
-            bw.push_back(op_ln_bwd(yN, mp.norm_w, mp.norm_b, m.stf[e], dxe, nullptr, g_cur, nullptr, d, 0,
+            float* g_cur = ar.f((size_t)T * dp);
+            bw.push_back(op_ln_bwd(yN, mp.norm_w, mp.norm_b, m.stf[e], dxe, nullptr, g_cur, nullptr, d, dp, 0,
                                    normp + (size_t)e * nblk * 2 * d));
             const float* gy = g_cur;
             const bool need_in = e > 0;          // gradient w.r.t. this encoder's input is needed
@@ -412,49 +428,49 @@ struct Builder {
                 const EncLayerBuf& b = m.L[e][l];
                 const bool first = (l == 0);
                 // LN2
-                float* ds2 = ar.f((size_t)T * d);
-                float* ds2m = b.site_d2 ? ar.f((size_t)T * d) : nullptr;
-                bw.push_back(op_ln_bwd(b.s2, p.n2_w, p.n2_b, b.st2, gy, nullptr, ds2, ds2m, d, b.site_d2));
+                float* ds2 = ar.f((size_t)T * dp);
+                float* ds2m = b.site_d2 ? ar.f((size_t)T * dp) : nullptr;
+                bw.push_back(op_ln_bwd(b.s2, p.n2_w, p.n2_b, b.st2, gy, nullptr, ds2, ds2m, d, dp, b.site_d2));
                 const float* ds2g = ds2m ? ds2m : ds2;
-                wgrad(ds2g, d, b.h, F, d, F, p.l2_w, F, (long)p.l2_b);
-                float* dh = ar.f((size_t)T * F);
+                wgrad(ds2g, dp, b.h, Fp, d, F, p.l2_w, F, (long)p.l2_b);
+                float* dh = ar.f((size_t)T * Fp);
                 {
-                    GemmProblem g = gp_make(ds2g, d, W(p.l2_w), F, T, F, d, dh, F);
-                    g.gate = b.h; g.ldgate = F; g.gate_scale = b.site_ff ? P.drop_scale : 1.f;
+                    GemmProblem g = gp_make(ds2g, dp, W(p.l2_w), F, T, F, d, dh, Fp);
+                    g.gate = b.h; g.ldgate = Fp; g.gate_scale = b.site_ff ? P.drop_scale : 1.f;
                     bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
                 }
-                wgrad(dh, F, b.y1, d, F, d, p.l1_w, d, (long)p.l1_b);
-                float* dy1 = ar.f((size_t)T * d);
+                wgrad(dh, Fp, b.y1, dp, F, d, p.l1_w, d, (long)p.l1_b);
+                float* dy1 = ar.f((size_t)T * dp);
                 {
-                    GemmProblem g = gp_make(dh, F, W(p.l1_w), d, T, d, F, dy1, d);
-                    g.res = ds2; g.ldres = d;
+                    GemmProblem g = gp_make(dh, Fp, W(p.l1_w), d, T, d, F, dy1, dp);
+                    g.res = ds2; g.ldres = dp;
                     bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
                 }
                 // LN1 (+ the encoder-level residual d x_{e-1} += d x_e on the first layer)
                 const float* extra = (first && need_in) ? dxe : nullptr;
-                float* ds1 = ar.f((size_t)T * d);
-                float* ds1m = (b.site_d1 || extra) ? ar.f((size_t)T * d) : nullptr;
-                bw.push_back(op_ln_bwd(b.s1, p.n1_w, p.n1_b, b.st1, dy1, extra, ds1, ds1m, d, b.site_d1));
+                float* ds1 = ar.f((size_t)T * dp);
+                float* ds1m = (b.site_d1 || extra) ? ar.f((size_t)T * dp) : nullptr;
+                bw.push_back(op_ln_bwd(b.s1, p.n1_w, p.n1_b, b.st1, dy1, extra, ds1, ds1m, d, dp, b.site_d1));
                 const float* ds1g = ds1m ? ds1m : ds1;
-                wgrad(ds1g, d, b.att, d, d, d, p.out_w, d, (long)p.out_b);
-                float* datt = ar.f((size_t)T * d);
-                bw.push_back(op_gemm(M2F_LAYOUT_NN, gp_make(ds1g, d, W(p.out_w), d, T, d, d, datt, d)));
-                float* dqkv = ar.f((size_t)T * 3 * d);
+                wgrad(ds1g, dp, b.att, dp, d, d, p.out_w, d, (long)p.out_b);
+                float* datt = ar.f((size_t)T * dp);
+                bw.push_back(op_gemm(M2F_LAYOUT_NN, gp_make(ds1g, dp, W(p.out_w), d, T, d, d, datt, dp)));
+                float* dqkv = ar.f((size_t)T * d3p);
                 {
                     Op o; o.kind = OP_ATTN_BWD;
                     AttnProblem a; memset(&a, 0, sizeof(a));
-                    a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
-                    a.out = b.att; a.ldo = d; a.probs = b.probs; a.H = H; a.hd = d / H; a.drop_site = b.site_attn;
-                    a.dout = datt; a.lddo = d;
-                    a.dq = dqkv; a.dk = dqkv + d; a.dv = dqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
+                    a.q = b.qkv; a.k = b.qkv + d; a.v = b.qkv + 2 * d; a.ldq = a.ldk = a.ldv = d3p;
+                    a.out = b.att; a.ldo = dp; a.probs = b.probs; a.H = H; a.hd = d / H; a.drop_site = b.site_attn;
+                    a.dout = datt; a.lddo = dp;
+                    a.dq = dqkv; a.dk = dqkv + d; a.dv = dqkv + 2 * d; a.lddq = a.lddk = a.lddv = d3p;
                     o.ap.push_back(a);
                     bw.push_back(o);
                 }
-                wgrad(dqkv, 3 * d, b.y_in, d, 3 * d, d, p.in_w, d, (long)p.in_b);
+                wgrad(dqkv, d3p, b.y_in, dp, 3 * d, d, p.in_w, d, (long)p.in_b);
                 if (!first || need_in) {
-                    float* gn = ar.f((size_t)T * d);
-                    GemmProblem g = gp_make(dqkv, 3 * d, W(p.in_w), d, T, d, 3 * d, gn, d);
-                    g.res = ds1; g.ldres = d;            // ds1 already carries the encoder-level residual
+                    float* gn = ar.f((size_t)T * dp);
+                    GemmProblem g = gp_make(dqkv, d3p, W(p.in_w), d, T, d, 3 * d, gn, dp);
+                    g.res = ds1; g.ldres = dp;            // ds1 already carries the encoder-level residual
                     bw.push_back(op_gemm(M2F_LAYOUT_NN, g));
                     gy = gn;
                 }
@@ -468,18 +484,19 @@ struct Builder {
     void build_head() {
         const m2f_config& c = P.cfg;
         const int E = c.d_fam, Hf = c.nhead_fam;
+        const int Ep = pad8(E), E2p = pad8(2 * E);
         const bool a_on = c.audio_enabled, t_on = c.text_enabled;
         const float* a = a_on ? mod[0].xp : nullptr;
         const float* t = t_on ? mod[1].xp : nullptr;
         if (c.fam_enabled) {
             // all K projections read the same (layer-invariant) audio tensor: one grouped launch per 8 layers
             std::vector<float*> kbuf;
-            for (int i = 0; i < c.nlayers_fam; ++i) kbuf.push_back(ar.f((size_t)T * E));
+            for (int i = 0; i < c.nlayers_fam; ++i) kbuf.push_back(ar.f((size_t)T * Ep));
             for (int i0 = 0; i0 < c.nlayers_fam; i0 += M2F_GEMM_MAX_PROBLEMS) {
                 Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NT;
                 for (int i = i0; i < std::min(c.nlayers_fam, i0 + M2F_GEMM_MAX_PROBLEMS); ++i) {
                     const FamP& p = P.pm.fam[i];
-                    GemmProblem g = gp_make(a, E, W(p.in_w + (size_t)E * E), E, T, E, E, kbuf[i], E);
+                    GemmProblem g = gp_make(a, Ep, W(p.in_w + (size_t)E * E), E, T, E, E, kbuf[i], Ep);
                     g.bias = W(p.in_b + E);
                     o.gp.push_back(g);
                 }
@@ -489,18 +506,18 @@ struct Builder {
                 const FamP& p = P.pm.fam[i];
                 FamBuf b;
                 b.t_in = t;
-                b.qv = ar.f((size_t)T * 2 * E);
+                b.qv = ar.f((size_t)T * E2p);
                 b.k = kbuf[i];
                 b.probs = ar.f(m2f_attn_probs_elems(P.B, Hf, P.L));
-                b.att = ar.f((size_t)T * E);
-                b.x = ar.f((size_t)T * E);
-                b.t_out = ar.f((size_t)T * E);
+                b.att = ar.f((size_t)T * Ep);
+                b.x = ar.f((size_t)T * Ep);
+                b.t_out = ar.f((size_t)T * Ep);
                 b.site_attn = site(); b.site_out = site();
                 {   // q = t Wq^T + bq -> qv[:, :E] ; v = t Wv^T + bv -> qv[:, E:]
                     Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NT;
-                    GemmProblem gq = gp_make(t, E, W(p.in_w), E, T, E, E, b.qv, 2 * E);
+                    GemmProblem gq = gp_make(t, Ep, W(p.in_w), E, T, E, E, b.qv, E2p);
                     gq.bias = W(p.in_b);
-                    GemmProblem gv = gp_make(t, E, W(p.in_w + (size_t)2 * E * E), E, T, E, E, b.qv + E, 2 * E);
+                    GemmProblem gv = gp_make(t, Ep, W(p.in_w + (size_t)2 * E * E), E, T, E, E, b.qv + E, E2p);
                     gv.bias = W(p.in_b + 2 * E);
                     o.gp.push_back(gq); o.gp.push_back(gv);
                     chain_f.push_back(o);
@@ -508,19 +525,19 @@ struct Builder {
                 {
                     Op o; o.kind = OP_ATTN_FWD;
                     AttnProblem at; memset(&at, 0, sizeof(at));
-                    at.q = b.qv; at.ldq = 2 * E; at.k = b.k; at.ldk = E; at.v = b.qv + E; at.ldv = 2 * E;
-                    at.out = b.att; at.ldo = E; at.probs = b.probs; at.H = Hf; at.hd = E / Hf; at.drop_site = b.site_attn;
+                    at.q = b.qv; at.ldq = E2p; at.k = b.k; at.ldk = Ep; at.v = b.qv + E; at.ldv = E2p;
+                    at.out = b.att; at.ldo = Ep; at.probs = b.probs; at.H = Hf; at.hd = E / Hf; at.drop_site = b.site_attn;
                     o.ap.push_back(at);
                     chain_f.push_back(o);
                 }
                 {
-                    GemmProblem g = gp_make(b.att, E, W(p.out_w), E, T, E, E, b.x, E);
+                    GemmProblem g = gp_make(b.att, Ep, W(p.out_w), E, T, E, E, b.x, Ep);
                     g.bias = W(p.out_b);
                     chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
                 }
                 {   // relu(Linear(relu(cat(x, t)))) -> dropout   (src/model.py:16-19,131)
-                    GemmProblem g = gp_make(b.x, E, W(p.lin_w), 2 * E, T, E, E, b.t_out, E);
-                    gp_seg2(g, t, E, W(p.lin_w) + E, 2 * E, E);
+                    GemmProblem g = gp_make(b.x, Ep, W(p.lin_w), 2 * E, T, E, E, b.t_out, Ep);
+                    gp_seg2(g, t, Ep, W(p.lin_w) + E, 2 * E, E);
                     g.bias = W(p.lin_b); g.flags |= GF_RELU_A | GF_RELU_OUT; g.drop_site = b.site_out;
                     chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
                 }
@@ -531,22 +548,23 @@ struct Builder {
         }
         // classifier (src/model.py:89-100,143): Linear0, [ReLU, Linear]*(n-2), ReLU, Dropout, Linear
         const int hid = c.cls_hidden, C = c.cls_out;
+        const int hidp = pad8(hid);
         const int nhid = (int)P.pm.cls.size() - 1;           // hidden activations h[0..nhid-1]
         std::vector<float*> hbuf;
         std::vector<uint32_t> hsite;
         const float* s0 = (a_on && t_on) ? a : (t_on ? t : a);
         const float* s1 = (a_on && t_on) ? t : nullptr;
         for (int j = 0; j < nhid; ++j) {
-            float* h = ar.f((size_t)T * hid);
+            float* h = ar.f((size_t)T * hidp);
             const uint32_t s = (j == nhid - 1) ? site() : 0u;
             const LinP& lp = P.pm.cls[j];
             GemmProblem g;
             if (j == 0) {
                 const int ldw = cls_in_width(c);
-                g = gp_make(s0, E, W(lp.w), ldw, T, hid, E, h, hid);
-                if (s1) gp_seg2(g, s1, E, W(lp.w) + E, ldw, E);
+                g = gp_make(s0, Ep, W(lp.w), ldw, T, hid, E, h, hidp);
+                if (s1) gp_seg2(g, s1, Ep, W(lp.w) + E, ldw, E);
             } else {
-                g = gp_make(hbuf[j - 1], hid, W(lp.w), hid, T, hid, hid, h, hid);
+                g = gp_make(hbuf[j - 1], hidp, W(lp.w), hid, T, hid, hid, h, hidp);
             }
             g.bias = W(lp.b); g.flags |= GF_RELU_OUT; g.drop_site = s;
             chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
@@ -557,7 +575,7 @@ struct Builder {
         P.bufs[M2F_BUF_LOGITS] = logits;
         {
             const LinP& lp = P.pm.cls[nhid];
-            GemmProblem g = gp_make(hbuf[nhid - 1], hid, W(lp.w), hid, T, C, hid, logits, C);
+            GemmProblem g = gp_make(hbuf[nhid - 1], hidp, W(lp.w), hid, T, C, hid, logits, C);
             g.bias = W(lp.b);
             chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
         }
@@ -576,43 +594,43 @@ struct Builder {
         const float gs = gscale();
         {   // last linear
             const LinP& lp = P.pm.cls[nhid];
-            wgrad(dlogits, C, hbuf[nhid - 1], hid, C, hid, lp.w, hid, (long)lp.b);
+            wgrad(dlogits, C, hbuf[nhid - 1], hidp, C, hid, lp.w, hid, (long)lp.b);
         }
-        float* dh = ar.f((size_t)T * hid);
+        float* dh = ar.f((size_t)T * hidp);
         {
             const LinP& lp = P.pm.cls[nhid];
-            GemmProblem g = gp_make(dlogits, C, W(lp.w), hid, T, hid, C, dh, hid);
-            g.gate = hbuf[nhid - 1]; g.ldgate = hid; g.gate_scale = hsite[nhid - 1] ? gs : 1.f;
+            GemmProblem g = gp_make(dlogits, C, W(lp.w), hid, T, hid, C, dh, hidp);
+            g.gate = hbuf[nhid - 1]; g.ldgate = hidp; g.gate_scale = hsite[nhid - 1] ? gs : 1.f;
             chain_b.push_back(op_gemm(M2F_LAYOUT_NN, g));
         }
         for (int j = nhid - 1; j >= 1; --j) {
             const LinP& lp = P.pm.cls[j];
-            wgrad(dh, hid, hbuf[j - 1], hid, hid, hid, lp.w, hid, (long)lp.b);
-            float* dprev = ar.f((size_t)T * hid);
-            GemmProblem g = gp_make(dh, hid, W(lp.w), hid, T, hid, hid, dprev, hid);
-            g.gate = hbuf[j - 1]; g.ldgate = hid; g.gate_scale = 1.f;
+            wgrad(dh, hidp, hbuf[j - 1], hidp, hid, hid, lp.w, hid, (long)lp.b);
+            float* dprev = ar.f((size_t)T * hidp);
+            GemmProblem g = gp_make(dh, hidp, W(lp.w), hid, T, hid, hid, dprev, hidp);
+            g.gate = hbuf[j - 1]; g.ldgate = hidp; g.gate_scale = 1.f;
             chain_b.push_back(op_gemm(M2F_LAYOUT_NN, g));
             dh = dprev;
         }
         // Linear0: input = cat(a, t) | t | a
         const LinP& l0 = P.pm.cls[0];
         const int ldw0 = cls_in_width(c);
-        float* d_a = a_on ? ar.f((size_t)T * E) : nullptr;
-        float* d_t = t_on ? ar.f((size_t)T * E) : nullptr;
+        float* d_a = a_on ? ar.f((size_t)T * Ep) : nullptr;
+        float* d_t = t_on ? ar.f((size_t)T * Ep) : nullptr;
         {
             Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NN;
             if (a_on && t_on) {
-                wgrad(dh, hid, a, E, hid, E, l0.w, ldw0, (long)l0.b);
-                wgrad(dh, hid, t, E, hid, E, l0.w + E, ldw0, -1);
-                o.gp.push_back(gp_make(dh, hid, W(l0.w), ldw0, T, E, hid, d_a, E));
-                GemmProblem g = gp_make(dh, hid, W(l0.w) + E, ldw0, T, E, hid, d_t, E);
-                if (c.fam_enabled) { g.gate = t; g.ldgate = E; g.gate_scale = fam.back().site_out ? gs : 1.f; }
+                wgrad(dh, hidp, a, Ep, hid, E, l0.w, ldw0, (long)l0.b);
+                wgrad(dh, hidp, t, Ep, hid, E, l0.w + E, ldw0, -1);
+                o.gp.push_back(gp_make(dh, hidp, W(l0.w), ldw0, T, E, hid, d_a, Ep));
+                GemmProblem g = gp_make(dh, hidp, W(l0.w) + E, ldw0, T, E, hid, d_t, Ep);
+                if (c.fam_enabled) { g.gate = t; g.ldgate = Ep; g.gate_scale = fam.back().site_out ? gs : 1.f; }
                 o.gp.push_back(g);
             } else {
                 const float* x = t_on ? t : a;
                 float* dx = t_on ? d_t : d_a;
-                wgrad(dh, hid, x, E, hid, E, l0.w, ldw0, (long)l0.b);
-                o.gp.push_back(gp_make(dh, hid, W(l0.w), ldw0, T, E, hid, dx, E));
+                wgrad(dh, hidp, x, Ep, hid, E, l0.w, ldw0, (long)l0.b);
+                o.gp.push_back(gp_make(dh, hidp, W(l0.w), ldw0, T, E, hid, dx, Ep));
             }
             chain_b.push_back(o);
         }
@@ -622,47 +640,47 @@ struct Builder {
         for (int i = (int)fam.size() - 1; i >= 0; --i) {
             const FamP& p = P.pm.fam[i];
             const FamBuf& b = fam[i];
-            wgrad(dz, E, b.x, E, E, E, p.lin_w, 2 * E, (long)p.lin_b, true);
-            wgrad(dz, E, b.t_in, E, E, E, p.lin_w + E, 2 * E, -1, true);
-            float* dx = ar.f((size_t)T * E);
-            float* dtA = ar.f((size_t)T * E);
+            wgrad(dz, Ep, b.x, Ep, E, E, p.lin_w, 2 * E, (long)p.lin_b, true);
+            wgrad(dz, Ep, b.t_in, Ep, E, E, p.lin_w + E, 2 * E, -1, true);
+            float* dx = ar.f((size_t)T * Ep);
+            float* dtA = ar.f((size_t)T * Ep);
             {
                 Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NN;
-                GemmProblem g1 = gp_make(dz, E, W(p.lin_w), 2 * E, T, E, E, dx, E);
-                g1.gate = b.x; g1.ldgate = E;
-                GemmProblem g2 = gp_make(dz, E, W(p.lin_w) + E, 2 * E, T, E, E, dtA, E);
-                g2.gate = b.t_in; g2.ldgate = E;
+                GemmProblem g1 = gp_make(dz, Ep, W(p.lin_w), 2 * E, T, E, E, dx, Ep);
+                g1.gate = b.x; g1.ldgate = Ep;
+                GemmProblem g2 = gp_make(dz, Ep, W(p.lin_w) + E, 2 * E, T, E, E, dtA, Ep);
+                g2.gate = b.t_in; g2.ldgate = Ep;
                 o.gp.push_back(g1); o.gp.push_back(g2);
                 chain_b.push_back(o);
             }
-            wgrad(dx, E, b.att, E, E, E, p.out_w, E, (long)p.out_b);
-            float* datt = ar.f((size_t)T * E);
-            chain_b.push_back(op_gemm(M2F_LAYOUT_NN, gp_make(dx, E, W(p.out_w), E, T, E, E, datt, E)));
-            float* dqv = ar.f((size_t)T * 2 * E);
-            float* dk = ar.f((size_t)T * E);
+            wgrad(dx, Ep, b.att, Ep, E, E, p.out_w, E, (long)p.out_b);
+            float* datt = ar.f((size_t)T * Ep);
+            chain_b.push_back(op_gemm(M2F_LAYOUT_NN, gp_make(dx, Ep, W(p.out_w), E, T, E, E, datt, Ep)));
+            float* dqv = ar.f((size_t)T * E2p);
+            float* dk = ar.f((size_t)T * Ep);
             {
                 Op o; o.kind = OP_ATTN_BWD;
                 AttnProblem at; memset(&at, 0, sizeof(at));
-                at.q = b.qv; at.ldq = 2 * E; at.k = b.k; at.ldk = E; at.v = b.qv + E; at.ldv = 2 * E;
-                at.out = b.att; at.ldo = E; at.probs = b.probs; at.H = Hf; at.hd = E / Hf; at.drop_site = b.site_attn;
-                at.dout = datt; at.lddo = E;
-                at.dq = dqv; at.lddq = 2 * E; at.dv = dqv + E; at.lddv = 2 * E; at.dk = dk; at.lddk = E;
+                at.q = b.qv; at.ldq = E2p; at.k = b.k; at.ldk = Ep; at.v = b.qv + E; at.ldv = E2p;
+                at.out = b.att; at.ldo = Ep; at.probs = b.probs; at.H = Hf; at.hd = E / Hf; at.drop_site = b.site_attn;
+                at.dout = datt; at.lddo = Ep;
+                at.dq = dqv; at.lddq = E2p; at.dv = dqv + E; at.lddv = E2p; at.dk = dk; at.lddk = Ep;
                 o.ap.push_back(at);
                 chain_b.push_back(o);
             }
-            wgrad(dqv, 2 * E, b.t_in, E, E, E, p.in_w, E, (long)p.in_b);                                        // dWq, dbq
-            wgrad(dk, E, a, E, E, E, p.in_w + (size_t)E * E, E, (long)(p.in_b + E));                            // dWk, dbk
-            wgrad(dqv + E, 2 * E, b.t_in, E, E, E, p.in_w + (size_t)2 * E * E, E, (long)(p.in_b + 2 * E));      // dWv, dbv
-            float* dt = ar.f((size_t)T * E);
+            wgrad(dqv, E2p, b.t_in, Ep, E, E, p.in_w, E, (long)p.in_b);                                         // dWq, dbq
+            wgrad(dk, Ep, a, Ep, E, E, p.in_w + (size_t)E * E, E, (long)(p.in_b + E));                          // dWk, dbk
+            wgrad(dqv + E, E2p, b.t_in, Ep, E, E, p.in_w + (size_t)2 * E * E, E, (long)(p.in_b + 2 * E));       // dWv, dbv
+            float* dt = ar.f((size_t)T * Ep);
             {
                 Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_NN;
                 // d t_in = dq Wq + dv Wv + dtA   (then the previous layer's ReLU/dropout gate)
-                GemmProblem g = gp_make(dqv, 2 * E, W(p.in_w), E, T, E, E, dt, E);
-                gp_seg2(g, dqv + E, 2 * E, W(p.in_w + (size_t)2 * E * E), E, E);
-                g.res = dtA; g.ldres = E;
-                if (i > 0) { g.gate = b.t_in; g.ldgate = E; g.gate_scale = fam[i - 1].site_out ? gs : 1.f; }
+                GemmProblem g = gp_make(dqv, E2p, W(p.in_w), E, T, E, E, dt, Ep);
+                gp_seg2(g, dqv + E, E2p, W(p.in_w + (size_t)2 * E * E), E, E);
+                g.res = dtA; g.ldres = Ep;
+                if (i > 0) { g.gate = b.t_in; g.ldgate = Ep; g.gate_scale = fam[i - 1].site_out ? gs : 1.f; }
                 // d audio += dk Wk
-                GemmProblem ga = gp_make(dk, E, W(p.in_w + (size_t)E * E), E, T, E, E, d_a, E);
+                GemmProblem ga = gp_make(dk, Ep, W(p.in_w + (size_t)E * E), E, T, E, E, d_a, Ep);
                 ga.flags |= GF_ACCUM;
                 o.gp.push_back(g); o.gp.push_back(ga);
                 chain_b.push_back(o);
@@ -675,7 +693,7 @@ struct Builder {
             float* dxp = bi == 0 ? d_a : d_t;
             if (!dxp) continue;
             if (mod[bi].site_post) {
-                Op o; o.kind = OP_DROPOUT; o.dptr = dxp; o.dT = T; o.dd = E; o.dld = E; o.dsite = mod[bi].site_post;
+                Op o; o.kind = OP_DROPOUT; o.dptr = dxp; o.dT = T; o.dd = E; o.dld = Ep; o.dsite = mod[bi].site_post;
                 chain_b.push_back(o);
             }
             build_modality_bwd(bi, bi == 0 ? P.pm.audio : P.pm.text, dxp);
@@ -764,8 +782,9 @@ int build_plan(m2f_plan& P, char* ws_base) {
     bld.ar.base = ws_base;
     const int T = P.T;
     // host-visible input staging
-    P.bufs[M2F_BUF_TEXT] = bld.ar.f((size_t)T * std::max(c.d_text, 1));
-    P.bufs[M2F_BUF_AUDIO] = bld.ar.f((size_t)T * std::max(c.d_audio, 1));
+    // input staging rows are padded to a multiple of 8 floats (like every activation buffer)
+    P.bufs[M2F_BUF_TEXT] = bld.ar.f((size_t)T * Builder::pad8(std::max(c.d_text, 1)));
+    P.bufs[M2F_BUF_AUDIO] = bld.ar.f((size_t)T * Builder::pad8(std::max(c.d_audio, 1)));
     P.bufs[M2F_BUF_KEYPAD] = bld.ar.alloc<uint8_t>((size_t)T);
     P.bufs[M2F_BUF_LABELS] = bld.ar.alloc<int64_t>((size_t)T);
     P.bufs[M2F_BUF_CLASSW] = bld.ar.f(16);
@@ -816,7 +835,67 @@ int build_plan(m2f_plan& P, char* ws_base) {
             P.lnred.push_back(rb);
         }
     }
+    // ---- bf16 shadows: activation shadow = one bf16 per fp32 workspace element; parameter shadow = padded matrices
+    bld.ar.off = (bld.ar.off + 255) / 256 * 256;
+    const size_t ws_floats = bld.ar.off / 4;
+    uint16_t* shadow = bld.ar.alloc<uint16_t>(ws_floats);
+    uint16_t* wshadow = bld.ar.alloc<uint16_t>(P.pm.shadow_elems + 64);
     P.ws_used = bld.ar.off;
+    if (P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
+        const float* wsf = reinterpret_cast<const float*>(ws_base);
+        P.sh = {wsf, shadow, ws_floats};
+        P.wshadow = wshadow;
+        auto map_q = [&](GemmOperand& o) {
+            for (int sgm = 0; sgm < 2; ++sgm) {
+                o.q[sgm] = nullptr; o.ldq[sgm] = 0; o.qt[sgm] = nullptr; o.ldqt[sgm] = 0;
+                const float* p = o.p[sgm];
+                if (o.k[sgm] == 0 || !p) continue;
+                const float* dl = static_cast<const float*>(P.bufs[M2F_BUF_DLOGITS]);
+                if (p >= dl && p < dl + (size_t)T * c.cls_out) continue;          // written by the criterion kernel: no shadow
+                if (p >= wsf && p < wsf + ws_floats) { o.q[sgm] = shadow + (p - wsf); o.ldq[sgm] = o.ld[sgm]; continue; }
+                if (p >= P.params && p < P.params + P.pm.total) {
+                    const size_t idx = (size_t)(p - P.params);
+                    for (const ParamMap::Mat& m : P.pm.mats) {
+                        if (idx >= m.off && idx < m.off + (size_t)m.rows * m.cols && o.ld[sgm] == m.cols) {
+                            const size_t r = (idx - m.off) / m.cols, cc = (idx - m.off) % m.cols;
+                            o.ldq[sgm] = (m.cols + 7) & ~7;
+                            o.q[sgm] = wshadow + m.soff + r * o.ldq[sgm] + cc;
+                            o.ldqt[sgm] = (m.rows + 7) & ~7;                       // W^T shadow: [cols][pad8(rows)]
+                            o.qt[sgm] = wshadow + m.soff_t + cc * o.ldqt[sgm] + r;
+                            break;
+                        }
+                    }
+                }
+            }
+        };
+        for (std::vector<Launch>* ls : {&P.fwd, &P.bwd, &P.wg})
+            for (Launch& l : *ls) {
+                l.gb.sh = P.sh; l.ab.sh = P.sh; l.lb.sh = P.sh;
+                if (l.kind == OP_GEMM)
+                    for (int i = 0; i < l.gb.count; ++i) { map_q(l.gb.pr[i].a); map_q(l.gb.pr[i].b); }
+            }
+        // casts at the start of a forward: every 2-D parameter into its padded shadow, then the two input buffers
+        CastBatch cb;
+        memset(&cb, 0, sizeof(cb));
+        auto flush = [&]() { if (cb.count) { P.casts.push_back(cb); memset(&cb, 0, sizeof(cb)); } };
+        for (const ParamMap::Mat& m : P.pm.mats) {
+            cb.it[cb.count++] = {P.params + m.off, wshadow + m.soff, m.rows, m.cols, m.cols, (m.cols + 7) & ~7,
+                                 wshadow + m.soff_t, (m.rows + 7) & ~7};
+            if (cb.count == M2F_CAST_MAX_ITEMS) flush();
+        }
+        flush();
+        if (c.text_enabled) {
+            const int dp = Builder::pad8(c.d_text);
+            float* x = static_cast<float*>(P.bufs[M2F_BUF_TEXT]);
+            cb.it[cb.count++] = {x, shadow + (x - wsf), T, c.d_text, dp, dp, nullptr, 0};
+        }
+        if (c.audio_enabled) {
+            const int dp = Builder::pad8(c.d_audio);
+            float* x = static_cast<float*>(P.bufs[M2F_BUF_AUDIO]);
+            cb.it[cb.count++] = {x, shadow + (x - wsf), T, c.d_audio, dp, dp, nullptr, 0};
+        }
+        flush();
+    }
     return 0;
 }
 
@@ -863,7 +942,7 @@ int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s, size_t fir
             case OP_ATTN_BWD: e = m2f_launch_attn_bwd(l.ab, s); break;
             case OP_LN_FWD: e = m2f_launch_ln_fwd(l.lb, s); break;
             case OP_LN_BWD: e = m2f_launch_ln_bwd(l.lb, s); break;
-            case OP_DROPOUT: e = m2f_launch_dropout_inplace(l.dptr, l.dT, l.dd, l.dld, l.dsite, P.rng, P.drop_thresh, P.drop_scale, s); break;
+            case OP_DROPOUT: e = m2f_launch_dropout_inplace(l.dptr, l.dT, l.dd, l.dld, l.dsite, P.rng, P.drop_thresh, P.drop_scale, P.sh, s); break;
         }
         if (g_prof) g_prof->end();
         if (e != hipSuccess) return hipfail(e, "kernel launch");
@@ -1019,14 +1098,21 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
 }
 
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
-    if (phase == 0) return (int)plan->fwd.size();
+    if (phase == 0) return (int)(plan->fwd.size() + plan->casts.size());
     if (phase == 1) return 2;
     return (int)(plan->bwd.size() + plan->wg.size() + plan->lnred.size());
 }
 
-int m2f_forward(m2f_plan* plan, m2f_stream_t stream) {
-    return run_launches(*plan, plan->fwd, static_cast<hipStream_t>(stream));
+static int do_forward(m2f_plan& P, hipStream_t s) {
+    for (const CastBatch& cb : P.casts) {                      // bf16 mode only: refresh the parameter / input shadows
+        if (g_prof) g_prof->begin(10, 0.0);
+        M2F_HIP(m2f_launch_cast(cb, s));
+        if (g_prof) g_prof->end();
+    }
+    return run_launches(P, P.fwd, s);
 }
+
+int m2f_forward(m2f_plan* plan, m2f_stream_t stream) { return do_forward(*plan, static_cast<hipStream_t>(stream)); }
 
 int m2f_loss(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream) {
     return do_loss(*plan, label_smoothing, use_class_weights, normalise, static_cast<hipStream_t>(stream));
@@ -1036,7 +1122,7 @@ int m2f_backward(m2f_plan* plan, m2f_stream_t stream) { return do_backward(*plan
 
 static int step_body(m2f_plan& P, float ls, int cw, int normalise, hipStream_t s) {
     if (P.use_dropout) M2F_HIP(m2f_launch_rng_advance(P.rng, s));
-    if (int r = run_launches(P, P.fwd, s)) return r;
+    if (int r = do_forward(P, s)) return r;
     if (int r = do_loss(P, ls, cw, normalise, s)) return r;
     return do_backward(P, s);
 }
@@ -1110,7 +1196,9 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
              const float* b0, int ldb0, const float* b1, int ldb1, float* c, int ldc, const float* bias, const float* res,
              int ldres, const float* gate, int ldgate, float gate_scale, float* bias_grad, int relu_a, int relu_b,
              int relu_out, int accumulate, uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile,
-             float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles, m2f_stream_t stream) {
+             float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles,
+             const uint16_t* a0q, int ldaq0, const uint16_t* a1q, int ldaq1,
+             const uint16_t* b0q, int ldbq0, const uint16_t* b1q, int ldbq1, m2f_stream_t stream) {
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     GemmProblem p = gp_make(a0, lda0, b0, ldb0, M, N, K0, c, ldc);
@@ -1118,6 +1206,9 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
     p.bias = bias; p.res = res; p.ldres = ldres; p.gate = gate; p.ldgate = ldgate; p.gate_scale = gate_scale;
     p.bias_grad = bias_grad; p.drop_site = drop_site;
     p.flags = (relu_a ? GF_RELU_A : 0) | (relu_b ? GF_RELU_B : 0) | (relu_out ? GF_RELU_OUT : 0) | (accumulate ? GF_ACCUM : 0);
+    p.a.q[0] = a0q; p.a.ldq[0] = ldaq0; p.a.q[1] = a1q; p.a.ldq[1] = ldaq1;
+    p.b.q[0] = b0q; p.b.ldq[0] = ldbq0; p.b.q[1] = b1q; p.b.ldq[1] = ldbq1;
+    p.a.qt[0] = p.a.qt[1] = p.b.qt[0] = p.b.qt[1] = nullptr;
     gb.pr[0] = p; gb.count = 1; gb.rng = rng_state;
     gb.splitk_ws = splitk_ws; gb.splitk_cnt = splitk_tickets; gb.splitk_max_tiles = splitk_ws && splitk_tickets ? splitk_max_tiles : 0;
     if (drop_site) drop_params(drop_p, &gb.drop_thresh, &gb.drop_scale);

@@ -6,6 +6,7 @@
 // no atomics, no memset).
 #include "common.h"
 #include "ops.h"
+#include <algorithm>
 
 namespace {
 
@@ -46,6 +47,24 @@ __device__ __forceinline__ void row_store(const RowRegs<NV>& r, float* __restric
         }
     }
 }
+// bf16 shadow of a row (rows of shadowed buffers are 16-byte aligned in fp32, hence 8-byte aligned in bf16)
+template <int NV>
+__device__ __forceinline__ void row_store_bf16(const RowRegs<NV>& r, uint16_t* __restrict__ q, int d, int lane) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c + 3 < d) {
+            uint2 w;
+            w.x = (uint32_t)m2f_bf16_bits(r.v[j][0]) | ((uint32_t)m2f_bf16_bits(r.v[j][1]) << 16);
+            w.y = (uint32_t)m2f_bf16_bits(r.v[j][2]) | ((uint32_t)m2f_bf16_bits(r.v[j][3]) << 16);
+            if ((reinterpret_cast<uintptr_t>(q + c) & 7) == 0) *reinterpret_cast<uint2*>(q + c) = w;
+            else { q[c] = (uint16_t)w.x; q[c + 1] = (uint16_t)(w.x >> 16); q[c + 2] = (uint16_t)w.y; q[c + 3] = (uint16_t)(w.y >> 16); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < d) q[c + e] = m2f_bf16_bits(r.v[j][e]);
+        }
+    }
+}
 __device__ __forceinline__ bool is_vec(const void* p, int d) {
     return ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
 }
@@ -59,9 +78,11 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
         if (i < lb.count && (int)blockIdx.x >= lb.pr[i].block_begin) pi = i;
     const LnProblem& P = lb.pr[pi];
     const int d = P.d;
+    const int ld = P.ld ? P.ld : d;
     const int blk = (int)blockIdx.x - P.block_begin;
     const bool vec = is_vec(P.x, d) && is_vec(P.out, d) && is_vec(P.gamma, d) && is_vec(P.beta, d) &&
-                     (!P.res || is_vec(P.res, d));
+                     (!P.res || is_vec(P.res, d)) && ((ld & 3) == 0);
+    uint16_t* out16 = m2f_shadow_of(lb.sh, P.out);
     RowRegs<NV> g, be;
     row_load(g, P.gamma, d, vec, lane);
     row_load(be, P.beta, d, vec, lane);
@@ -72,7 +93,7 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
         const int row = blk * M2F_LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE + rr;
         if (row >= lb.T) break;                             // wave-uniform
         RowRegs<NV> x;
-        row_load(x, P.x + (size_t)row * d, d, vec, lane);
+        row_load(x, P.x + (size_t)row * ld, d, vec, lane);
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) s += (x.v[j][0] + x.v[j][1]) + (x.v[j][2] + x.v[j][3]);
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
             }
         const float rstd = 1.0f / sqrtf(m2f_wave_sum(q) * invd + lb.eps);
         RowRegs<NV> res;
-        if (P.res) row_load(res, P.res + (size_t)row * d, d, vec, lane);
+        if (P.res) row_load(res, P.res + (size_t)row * ld, d, vec, lane);
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -101,7 +122,8 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
                 }
                 x.v[j][e] = y;
             }
-        row_store(x, P.out + (size_t)row * d, d, vec, lane);
+        row_store(x, P.out + (size_t)row * ld, d, vec, lane);
+        if (out16) row_store_bf16(x, out16 + (size_t)row * ld, d, lane);
         if (lane == 0) { P.stats[2 * row] = mean; P.stats[2 * row + 1] = rstd; }
     }
 }
@@ -116,10 +138,13 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
         if (i < lb.count && (int)blockIdx.x >= lb.pr[i].block_begin) pi = i;
     const LnProblem& P = lb.pr[pi];
     const int d = P.d;
+    const int ld = P.ld ? P.ld : d;
     const int dpad = (d + 3) & ~3;
     const int blk = (int)blockIdx.x - P.block_begin;
     const bool vec = is_vec(P.x, d) && is_vec(P.dy, d) && is_vec(P.dx, d) && is_vec(P.gamma, d) &&
-                     (!P.extra || is_vec(P.extra, d)) && (!P.dx_masked || is_vec(P.dx_masked, d));
+                     (!P.extra || is_vec(P.extra, d)) && (!P.dx_masked || is_vec(P.dx_masked, d)) && ((ld & 3) == 0);
+    uint16_t* dx16 = m2f_shadow_of(lb.sh, P.dx);
+    uint16_t* dxm16 = P.dx_masked ? m2f_shadow_of(lb.sh, P.dx_masked) : nullptr;
     RowRegs<NV> g, dg, db;
     row_load(g, P.gamma, d, vec, lane);
 #pragma unroll
@@ -131,8 +156,8 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
         const int row = blk * M2F_LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE + rr;
         if (row >= lb.T) break;
         RowRegs<NV> x, dy;
-        row_load(x, P.x + (size_t)row * d, d, vec, lane);
-        row_load(dy, P.dy + (size_t)row * d, d, vec, lane);
+        row_load(x, P.x + (size_t)row * ld, d, vec, lane);
+        row_load(dy, P.dy + (size_t)row * ld, d, vec, lane);
         const float mean = P.stats[2 * row], rstd = P.stats[2 * row + 1];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
             }
         const float c1 = m2f_wave_sum(s1) * invd, c2 = m2f_wave_sum(s2) * invd;
         RowRegs<NV> ex;
-        if (P.extra) row_load(ex, P.extra + (size_t)row * d, d, vec, lane);
+        if (P.extra) row_load(ex, P.extra + (size_t)row * ld, d, vec, lane);
         RowRegs<NV> msk;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -165,8 +190,10 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
                 msk.v[j][e] = dm;
                 dy.v[j][e] = P.extra ? dx + ex.v[j][e] : dx;
             }
-        row_store(dy, P.dx + (size_t)row * d, d, vec, lane);
-        if (P.dx_masked) row_store(msk, P.dx_masked + (size_t)row * d, d, vec, lane);
+        row_store(dy, P.dx + (size_t)row * ld, d, vec, lane);
+        if (dx16) row_store_bf16(dy, dx16 + (size_t)row * ld, d, lane);
+        if (P.dx_masked) row_store(msk, P.dx_masked + (size_t)row * ld, d, vec, lane);
+        if (dxm16) row_store_bf16(msk, dxm16 + (size_t)row * ld, d, lane);
     }
     // per-block partial dgamma / dbeta: waves -> LDS -> fixed-order sum (deterministic)
     float* mine = red + (size_t)wave * 2 * dpad;
@@ -183,17 +210,29 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
     }
 }
 
+// one block = 64 columns of one LayerNorm; its 4 wavefronts each sum a quarter of the row-block partials, then a
+// fixed-order LDS combine (deterministic).  Grid (ceil(max_d / 64), items).
 __global__ __launch_bounds__(256) void m2f_ln_param_reduce_kernel(const LnReduceBatch rb) {
+    __shared__ float part[4][2][64];
     const LnReduceItem& it = rb.it[blockIdx.y];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= it.d) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < it.nblk; ++b) {
-        sg += it.partial[(size_t)b * 2 * it.d + c];
-        sb += it.partial[(size_t)b * 2 * it.d + it.d + c];
+    if (c < it.d) {
+        const int per = (it.nblk + 3) / 4;
+        const int b0 = w * per, b1 = b0 + per < it.nblk ? b0 + per : it.nblk;
+        for (int b = b0; b < b1; ++b) {
+            sg += it.partial[(size_t)b * 2 * it.d + c];
+            sb += it.partial[(size_t)b * 2 * it.d + it.d + c];
+        }
     }
-    it.dgamma[c] = sg;
-    it.dbeta[c] = sb;
+    part[w][0][lane] = sg;
+    part[w][1][lane] = sb;
+    __syncthreads();
+    if (w == 0 && c < it.d) {
+        it.dgamma[c] = (part[0][0][lane] + part[1][0][lane]) + (part[2][0][lane] + part[3][0][lane]);
+        it.dbeta[c] = (part[0][1][lane] + part[1][1][lane]) + (part[2][1][lane] + part[3][1][lane]);
+    }
 }
 
 // ---- criterion ---------------------------------------------------------------------------------------
@@ -260,13 +299,40 @@ __global__ __launch_bounds__(256) void m2f_loss_finalize_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void m2f_dropout_inplace_kernel(float* __restrict__ x, int T, int d, int ld, uint32_t site,
-                                                                  const uint32_t* __restrict__ rng, uint32_t thresh, float scale) {
+                                                                  const uint32_t* __restrict__ rng, uint32_t thresh, float scale,
+                                                                  ShadowMap sh) {
     const uint32_t key = m2f_site_key(rng, site);
     const size_t n = (size_t)T * d;
+    uint16_t* x16 = m2f_shadow_of(sh, x);
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
         const int r = (int)(e / d), c = (int)(e - (size_t)r * d);
         float* p = x + (size_t)r * ld + c;
-        *p = m2f_keep(key, (uint32_t)e, thresh) ? *p * scale : 0.f;
+        const float v = m2f_keep(key, (uint32_t)e, thresh) ? *p * scale : 0.f;
+        *p = v;
+        if (x16) x16[(size_t)r * ld + c] = m2f_bf16_bits(v);
+    }
+}
+
+// fp32 -> bf16 copies of 2-D blocks (parameter matrices into their padded shadows, input staging buffers)
+__global__ __launch_bounds__(256) void m2f_cast_kernel(const CastBatch cb) {
+    const CastItem& it = cb.it[blockIdx.y];
+    const size_t n4 = (size_t)it.rows * ((it.cols + 3) >> 2);
+    const int c4n = (it.cols + 3) >> 2;
+    const bool vec = ((it.cols & 3) == 0) && ((it.lds & 3) == 0) && ((it.ldd & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(it.src) & 15) == 0) && ((reinterpret_cast<uintptr_t>(it.dst) & 7) == 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / c4n), c = 4 * (int)(i - (size_t)r * c4n);
+        const float* s = it.src + (size_t)r * it.lds + c;
+        uint16_t* q = it.dst + (size_t)r * it.ldd + c;
+        if (vec) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(s);
+            uint2 w;
+            w.x = (uint32_t)m2f_bf16_bits(x[0]) | ((uint32_t)m2f_bf16_bits(x[1]) << 16);
+            w.y = (uint32_t)m2f_bf16_bits(x[2]) | ((uint32_t)m2f_bf16_bits(x[3]) << 16);
+            *reinterpret_cast<uint2*>(q) = w;
+        } else {
+            for (int e = 0; e < 4; ++e) if (c + e < it.cols) q[e] = m2f_bf16_bits(s[e]);
+        }
     }
 }
 
@@ -340,7 +406,7 @@ hipError_t m2f_launch_ln_param_reduce(const LnReduceBatch& rb, hipStream_t strea
     if (rb.count > M2F_LNRED_MAX_ITEMS) return hipErrorInvalidValue;
     int maxd = 0;
     for (int i = 0; i < rb.count; ++i) if (rb.it[i].d > maxd) maxd = rb.it[i].d;
-    hipLaunchKernelGGL(m2f_ln_param_reduce_kernel, dim3(m2f_cdiv(maxd, 256), rb.count), dim3(256), 0, stream, rb);
+    hipLaunchKernelGGL(m2f_ln_param_reduce_kernel, dim3(m2f_cdiv(maxd, 64), rb.count), dim3(256), 0, stream, rb);
     return hipGetLastError();
 }
 
@@ -357,11 +423,59 @@ hipError_t m2f_launch_loss_finalize(const float* loss_terms, int T, int C, float
 }
 
 hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
-                                      uint32_t thresh, float scale, hipStream_t stream) {
+                                      uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream) {
     const size_t n = (size_t)T * d;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(m2f_dropout_inplace_kernel, dim3(blocks), dim3(256), 0, stream, x, T, d, ld, site, rng, thresh, scale);
+    hipLaunchKernelGGL(m2f_dropout_inplace_kernel, dim3(blocks), dim3(256), 0, stream, x, T, d, ld, site, rng, thresh, scale, sh);
+    return hipGetLastError();
+}
+
+// same, plus the transposed bf16 copy (32x32 tiles through LDS so both copies are written in full 64-byte rows)
+__global__ __launch_bounds__(256) void m2f_cast_t_kernel(const CastBatch cb) {
+    __shared__ uint16_t tile[32][34];
+    const CastItem& it = cb.it[blockIdx.y];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    const int tiles_c = (it.cols + 31) >> 5, tiles_r = (it.rows + 31) >> 5;
+    for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+        const int r0 = (t / tiles_c) << 5, c0 = (t % tiles_c) << 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ty + 8 * i, c = c0 + tx;
+            uint16_t v = 0;
+            if (r < it.rows && c < it.cols) {
+                v = m2f_bf16_bits(it.src[(size_t)r * it.lds + c]);
+                it.dst[(size_t)r * it.ldd + c] = v;
+            }
+            tile[ty + 8 * i][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;                // transposed: row index of dst_t = column of src
+            if (c < it.cols && r < it.rows) it.dst_t[(size_t)c * it.ldd_t + r] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream) {
+    if (cb.count <= 0) return hipSuccess;
+    if (cb.count > M2F_CAST_MAX_ITEMS) return hipErrorInvalidValue;
+    bool transposed = true;
+    for (int i = 0; i < cb.count; ++i) transposed = transposed && cb.it[i].dst_t != nullptr;
+    if (transposed) {
+        size_t mt = 0;
+        for (int i = 0; i < cb.count; ++i) mt = std::max(mt, (size_t)((cb.it[i].rows + 31) / 32) * ((cb.it[i].cols + 31) / 32));
+        const int bx = (int)std::min<size_t>(std::max<size_t>(mt, 1), 256);
+        hipLaunchKernelGGL(m2f_cast_t_kernel, dim3(bx, cb.count), dim3(256), 0, stream, cb);
+        return hipGetLastError();
+    }
+    size_t mx = 0;
+    for (int i = 0; i < cb.count; ++i) mx = std::max(mx, (size_t)cb.it[i].rows * ((cb.it[i].cols + 3) / 4));
+    int bx = (int)std::min<size_t>((mx + 255) / 256, 512);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(m2f_cast_kernel, dim3(bx, cb.count), dim3(256), 0, stream, cb);
     return hipGetLastError();
 }
 

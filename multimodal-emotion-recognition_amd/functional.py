@@ -33,12 +33,19 @@ def _splitk_scratch(device):
     return _SPLITK[device]
 
 
+def _shadow16(t: torch.Tensor) -> torch.Tensor:
+    rows, cols = t.shape
+    out = torch.zeros(rows, (cols + 7) // 8 * 8, dtype=torch.bfloat16, device=t.device)
+    out[:, :cols] = t.to(torch.bfloat16)
+    return out
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, layout: int = NT, precision: int = runtime.F32,
          a1: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0,
          bias_grad: bool = False, relu_a: bool = False, relu_b: bool = False, relu_out: bool = False,
          out: Optional[torch.Tensor] = None, accumulate: bool = False, drop_site: int = 0, drop_p: float = 0.0,
-         rng: Optional[torch.Tensor] = None, tile: int = 0, split_k: bool = False):
+         rng: Optional[torch.Tensor] = None, tile: int = 0, split_k: bool = False, src16: bool = False):
     """layout NT: a[M,K] b[N,K]; NN: a[M,K] b[K,N]; TN: a[K,M] b[K,N].  Returns C (and bias_grad[M] for TN)."""
     runtime.require_gpu()
     if layout == NT:
@@ -53,11 +60,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: int = NT, precision: int = ru
     c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
     bg = torch.empty(M, dtype=torch.float32, device=a.device) if bias_grad else None
     ws, tickets, nmax = _splitk_scratch(a.device) if split_k else (None, None, 0)
+    # bf16 shadows (test plumbing: in the plan the producer kernels write them): zero-padded to a multiple of 8 columns
+    sh = [None if (t is None or not src16) else _shadow16(t) for t in (a, a1, b, b1)]
+    shp = [(ptr(t), t.stride(0)) if t is not None else (None, 0) for t in sh]
     check(lib().m2f_gemm(precision, layout, M, N, K0, K1, ptr(a), _ld(a), ptr(a1), _ld(a1) if a1 is not None else 0,
                          ptr(b), _ld(b), ptr(b1), _ld(b1) if b1 is not None else 0, ptr(c), _ld(c), ptr(bias),
                          ptr(res), _ld(res) if res is not None else 0, ptr(gate), _ld(gate) if gate is not None else 0,
                          gate_scale, ptr(bg), int(relu_a), int(relu_b), int(relu_out), int(accumulate), drop_site,
-                         drop_p, ptr(rng), tile, ptr(ws), ptr(tickets), nmax, stream_ptr()), "m2f_gemm")
+                         drop_p, ptr(rng), tile, ptr(ws), ptr(tickets), nmax, shp[0][0], shp[0][1], shp[1][0], shp[1][1],
+                         shp[2][0], shp[2][1], shp[3][0], shp[3][1], stream_ptr()), "m2f_gemm")
     return (c, bg) if bias_grad else c
 
 

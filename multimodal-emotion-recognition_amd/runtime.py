@@ -73,7 +73,7 @@ SIGNATURES = {
     "m2f_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                          c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float,
                          c_void_p, c_int, c_int, c_int, c_int, c_uint32, c_float, c_void_p, c_int, c_void_p, c_void_p,
-                         c_int, c_void_p]),
+                         c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "m2f_attention_fwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_void_p, c_uint32, c_float, c_void_p, c_void_p]),
     "m2f_attention_bwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
@@ -178,8 +178,9 @@ class Plan:
         if not self.handle:
             raise HipError("m2f_plan_create: " + lib().m2f_last_error().decode())
         C = cfg.cls_out
-        self.text_in = self._view(BUF_TEXT, (self.T, max(cfg.d_text, 1)), torch.float32)
-        self.audio_in = self._view(BUF_AUDIO, (self.T, max(cfg.d_audio, 1)), torch.float32)
+        pad8 = lambda w: (w + 7) // 8 * 8          # every activation row is padded to a multiple of 8 floats
+        self.text_in = self._view(BUF_TEXT, (self.T, pad8(max(cfg.d_text, 1))), torch.float32)[:, : max(cfg.d_text, 1)]
+        self.audio_in = self._view(BUF_AUDIO, (self.T, pad8(max(cfg.d_audio, 1))), torch.float32)[:, : max(cfg.d_audio, 1)]
         self.keypad_in = self._view(BUF_KEYPAD, (self.T,), torch.uint8)
         self.labels_in = self._view(BUF_LABELS, (self.T,), torch.int64)
         self.class_w = self._view(BUF_CLASSW, (16,), torch.float32)
@@ -192,7 +193,8 @@ class Plan:
         else:
             self.loss = self._view(BUF_LOSS, (4,), torch.float32)
         self.dlogits = self._view(BUF_DLOGITS, (B, L, C), torch.float32)
-        self.fam0_out = self._view(BUF_FAM0_OUT, (B, L, cfg.d_fam), torch.float32) if cfg.fam_enabled else None
+        self.fam0_out = (self._view(BUF_FAM0_OUT, (B, L, pad8(cfg.d_fam)), torch.float32)[..., : cfg.d_fam]
+                         if cfg.fam_enabled else None)
         self.version = 0          # bumped by every forward; backward checks it still owns the activations
 
     def _view(self, which: int, shape, dtype) -> torch.Tensor:

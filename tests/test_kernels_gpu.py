@@ -69,6 +69,32 @@ def test_gemm_split_k_matches_unsplit_and_is_reproducible(prec, shape):
     _close(got.double(), a.double() @ b.double().t() + a2.double() @ b2.double().t(), TOL[prec], "split-K two segments")
 
 
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", [(70, 50, 45), (512, 768, 768), (129, 300, 300), (512, 900, 300), (64, 7, 768), (33, 2048, 96),
+                                   (512, 768, 2048), (200, 304, 520)])
+def test_gemm_bf16_source_equals_fp32_source(tile, shape):
+    """bf16 mode staged from the bf16 shadows must give the SAME result as staging from fp32 (same rounding points)."""
+    M, N, K = shape
+    prec = runtime.BF16
+    a, b_nk = _rand(M, K, seed=1), _rand(N, K, seed=2)
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    ref = F.gemm(a, b_nk, F.NT, prec, bias=bias, res=res, relu_out=True, tile=tile)
+    got = F.gemm(a, b_nk, F.NT, prec, bias=bias, res=res, relu_out=True, tile=tile, src16=True)
+    _close(got, ref, 2e-6, "NT bf16-source")
+    b_kn = b_nk.t().contiguous()
+    _close(F.gemm(a, b_kn, F.NN, prec, tile=tile, src16=True), F.gemm(a, b_kn, F.NN, prec, tile=tile), 2e-6, "NN bf16-source")
+    a_km = a.t().contiguous()
+    c1, bg1 = F.gemm(a_km, b_kn, F.TN, prec, tile=tile, bias_grad=True, src16=True)
+    c0, bg0 = F.gemm(a_km, b_kn, F.TN, prec, tile=tile, bias_grad=True)
+    _close(c1, c0, 2e-6, "TN bf16-source")
+    _close(bg1, a_km.to(torch.bfloat16).float().sum(dim=0), 1e-5, "bias grad from bf16 operands")
+    # relu prologue + two segments
+    a2, b2 = _rand(M, 64, seed=5), _rand(N, 64, seed=6)
+    r0 = F.gemm(a, b_nk, F.NT, prec, a1=a2, b1=b2, relu_a=True, tile=tile)
+    r1 = F.gemm(a, b_nk, F.NT, prec, a1=a2, b1=b2, relu_a=True, tile=tile, src16=True)
+    _close(r1, r0, 2e-6, "two segments + relu prologue")
+
+
 @pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
 def test_gemm_epilogue_and_segments(prec):
     M, N, K0, K1 = 96, 80, 64, 40

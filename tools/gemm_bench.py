@@ -12,26 +12,27 @@ SHAPES = [  # (name, layout, M, N, K)
     ("wgrad TN", F.TN, 768, 768, 512), ("wffn  TN", F.TN, 2048, 768, 512), ("wqkv  TN", F.TN, 2304, 768, 512),
 ]
 
-def run(prec, tile, iters=200):
+def run(prec, tile, iters=200, src16=False):
+    KW = {}
     for name, lay, M, N, K in SHAPES:
         if lay == F.NT: a, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
         elif lay == F.NN: a, b = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda")
         else: a, b = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda")
         out = torch.empty(M, N, device="cuda")
         flush = torch.empty(64 * 1024 * 1024, device="cuda")   # 256 MB: evict L2/MALL between timed launches
-        for _ in range(3): F.gemm(a, b, lay, prec, out=out, tile=tile)
+        for _ in range(3): F.gemm(a, b, lay, prec, out=out, tile=tile, **KW)
         torch.cuda.synchronize()
         # warm (back-to-back) timing
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters): F.gemm(a, b, lay, prec, out=out, tile=tile)
+        for _ in range(iters): F.gemm(a, b, lay, prec, out=out, tile=tile, **KW)
         e1.record(); torch.cuda.synchronize()
         warm = e0.elapsed_time(e1) / iters * 1e3
         # cold timing: flush caches before each launch
         tot = 0.0
         for _ in range(20):
             flush.zero_()
-            e0.record(); F.gemm(a, b, lay, prec, out=out, tile=tile); e1.record(); torch.cuda.synchronize()
+            e0.record(); F.gemm(a, b, lay, prec, out=out, tile=tile, **KW); e1.record(); torch.cuda.synchronize()
             tot += e0.elapsed_time(e1)
         cold = tot / 20 * 1e3
         fl = 2.0 * M * N * K

@@ -17,24 +17,52 @@
 
 namespace {
 
+// [Lp x W] zero-padded LDS copy of src rows [0, L) x cols [0, hd).  Loads are UNCONDITIONAL (clamped address +
+// select) and issued in batches of up to 8 per lane before any LDS write, so a slab costs about one memory round
+// trip instead of one per 16-byte piece (guarded loads compile to branch + s_waitcnt vmcnt(0) each).
 __device__ __forceinline__ void load_slab(float* __restrict__ lds, int ld, int Lp, int W,
                                           const float* __restrict__ src, int ldg, int L, int hd,
                                           int lane) {
-    // [Lp x W] zero-padded copy of src rows [0, L) x cols [0, hd)
     const bool vec = ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     if (vec) {
-        const int C4 = W >> 2;
-        for (int e = lane; e < Lp * C4; e += 64) {
-            const int r = e / C4, c = (e - r * C4) << 2;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (r < L && c < hd) x = *reinterpret_cast<const f32x4*>(src + (size_t)r * ldg + c);
-            float* d = lds + r * ld + c;
-            d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
+        const int C4 = W >> 2, total = Lp * C4;
+        for (int base = 0; base < total; base += 64 * 8) {
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + lane + 64 * u;
+                const int r = e / C4, c = (e - r * C4) << 2;
+                const bool ok = e < total && r < L && c < hd;
+                x[u] = *reinterpret_cast<const f32x4*>(src + (ok ? (size_t)r * ldg + c : (size_t)0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + lane + 64 * u;
+                const int r = e / C4, c = (e - r * C4) << 2;
+                if (e < total) {
+                    const bool ok = r < L && c < hd;
+                    float* d = lds + r * ld + c;
+                    d[0] = ok ? x[u][0] : 0.f; d[1] = ok ? x[u][1] : 0.f; d[2] = ok ? x[u][2] : 0.f; d[3] = ok ? x[u][3] : 0.f;
+                }
+            }
         }
     } else {
-        for (int e = lane; e < Lp * W; e += 64) {
-            const int r = e / W, c = e - r * W;
-            lds[r * ld + c] = (r < L && c < hd) ? src[(size_t)r * ldg + c] : 0.f;
+        const int total = Lp * W;
+        for (int base = 0; base < total; base += 64 * 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + lane + 64 * u;
+                const int r = e / W, c = e - r * W;
+                const bool ok = e < total && r < L && c < hd;
+                x[u] = src[ok ? (size_t)r * ldg + c : (size_t)0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + lane + 64 * u;
+                const int r = e / W, c = e - r * W;
+                if (e < total) lds[r * ld + c] = (r < L && c < hd) ? x[u] : 0.f;
+            }
         }
     }
 }
@@ -170,15 +198,18 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
     load_slab(Vs, ld, Lp, W, P.v + tok0 * P.ldv + h * hd, P.ldv, L, hd, lane);
     load_slab(Gs, ld, Lp, W, P.dout + tok0 * P.lddo + h * hd, P.lddo, L, hd, lane);
     __syncthreads();
-    // delta_i = sum_c dO[i][c] * O[i][c]  (= sum_j P[i][j] dP[i][j], also under dropout)
-    if (lane < Lp) {
+    // delta_i = sum_c dO[i][c] * O[i][c]  (= sum_j P[i][j] dP[i][j], also under dropout).  Four lanes per row, each
+    // streams a quarter of the row of O from global memory (unconditional clamped loads), shuffle-reduce over the 4.
+    for (int r0 = 0; r0 < Lp; r0 += 16) {
+        const int row = r0 + (lane >> 2), part = lane & 3;
+        const bool rok = row < L;
+        const float* o = P.out + (tok0 + (rok ? row : 0)) * P.ldo + h * hd;
+        const float* g = Gs + row * ld;
         float d = 0.f;
-        if (lane < L) {
-            const float* o = P.out + (tok0 + lane) * P.ldo + h * hd;
-            const float* g = Gs + lane * ld;
-            for (int c = 0; c < hd; ++c) d += g[c] * o[c];
-        }
-        delta[lane] = d;
+        for (int c = part; c < hd; c += 4) d += g[c] * o[c];
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        if (part == 0) delta[row] = rok ? d : 0.f;
     }
     __syncthreads();
 

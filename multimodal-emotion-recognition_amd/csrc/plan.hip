@@ -816,13 +816,20 @@ int build_plan(m2f_plan& P, char* ws_base) {
         std::vector<std::pair<int, size_t>> order;
         for (size_t i = 0; i < bld.wgrads.size(); ++i) order.push_back({final_index(bld.wdeps[i]), i});
         std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        // groups of up to 8 problems; a problem that cannot be staged from bf16 shadows (leading dimension not a
+        // multiple of 8: the [T, n_classes] criterion gradient) gets a launch of its own instead of dragging seven
+        // others onto the fp32-source path
         std::vector<Op> wops;
-        for (size_t i = 0; i < order.size(); i += M2F_GEMM_MAX_PROBLEMS) {
+        auto shadowable = [](const GemmProblem& g) { return !(g.a.ld[0] & 7) && !(g.b.ld[0] & 7); };
+        size_t i = 0;
+        while (i < order.size()) {
             Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
             int dep = -1;
-            for (size_t j = i; j < std::min(order.size(), i + M2F_GEMM_MAX_PROBLEMS); ++j) {
-                o.gp.push_back(bld.wgrads[order[j].second]);
-                dep = std::max(dep, order[j].first);
+            const bool kind0 = shadowable(bld.wgrads[order[i].second]);
+            while (i < order.size() && o.gp.size() < M2F_GEMM_MAX_PROBLEMS && shadowable(bld.wgrads[order[i].second]) == kind0) {
+                o.gp.push_back(bld.wgrads[order[i].second]);
+                dep = std::max(dep, order[i].first);
+                ++i;
             }
             wops.push_back(o);
             P.wg_dep.push_back(dep);

@@ -218,7 +218,7 @@ def main():
             eval_cfg = dict(cfg, dropout=0.0)
             out["cpu_baseline"] = cpu_baseline(eval_cfg, B, L, args.cpu_budget)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -28,7 +28,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ        # under torchrun (also with one rank)
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -36,9 +37,22 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
+        # RCCL prints a version banner on STDOUT when the communicator is created (lazily, at the first collective);
+        # callers such as bench.py own stdout (one JSON line), so create it now with stdout pointed at stderr.
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
             dist.init_process_group(backend, rank=rank, world_size=world)
+            probe = torch.zeros(1, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, world, local
 
 
@@ -75,8 +89,8 @@ class GradReducer:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def all_reduce(self, async_op: bool = False) -> None:
-        if self.world() == 1:
-            return
+        if not dist.is_initialized():
+            return                                   # single process: nothing to exchange
         self._work = [dist.all_reduce(self.buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                       for a, b in self.chunks]
         if not async_op:

@@ -272,6 +272,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
     }
 }
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own
+// L2), so consecutive blocks never share an L2.  Remap b -> pos so that every XCD walks a CONTIGUOUS range of the
+// launch's tile list, and order tiles with the M index fastest: an XCD then owns whole column panels of B (the weight,
+// cold in HBM), which are fetched into one L2 once instead of into all eight.  Bijective for any grid size; a different
+// hardware placement only changes speed, never results.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, x = b & 7, j = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 // LDS-only workgroup barrier: wait for this wave's LDS traffic, then s_barrier.  __syncthreads() carries a
 // workgroup-scope fence for which hipcc also drains vmcnt(0), i.e. the prefetched global loads of the next
 // k-tiles - exactly the loads that must stay in flight across the barrier.
@@ -631,14 +641,16 @@ __global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int bpos = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_GEMM_MAX_PROBLEMS; ++i)
-        if (i < gb.count && (int)blockIdx.x >= gb.pr[i].tile_begin) pi = i;
+        if (i < gb.count && bpos >= gb.pr[i].tile_begin) pi = i;
     const GemmProblem& P = gb.pr[pi];
     const int M = P.M, N = P.N;
-    const int tl = (int)blockIdx.x - P.tile_begin;
-    const int m0 = (tl / P.tiles_n) * BM, n0 = (tl % P.tiles_n) * BN;
+    const int tl = bpos - P.tile_begin;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;       // M fastest: neighbours share the B panel
     const uint32_t flags = P.flags;
     const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
     const int nk0 = (P.a.k[0] + BK - 1) / BK, nk = nk0 + (P.a.k[1] + BK - 1) / BK;

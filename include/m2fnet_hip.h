@@ -91,6 +91,13 @@ int m2f_backward(m2f_plan* plan, m2f_stream_t stream);
 int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, int use_graph,
              m2f_stream_t stream);
 
+/* Device-side dialogue batcher: Dataset.__getitem__ + collate_fn / apply_padding (src/dataset.py:32-89, src/utils.py:15-31)
+ * on device-resident embedding tables.  Token slot t receives row rows[t] of each table; rows[t] < 0 marks a padded slot
+ * (features 0, label -1, key_pad 1).  Outputs may be a plan's staging buffers (row strides ld_text / ld_audio). */
+int m2f_gather_dialogues(const float* text_table, int d_text, const float* audio_table, int d_audio,
+                         const int64_t* label_table, const int32_t* rows, int T, float* text_out, int ld_text,
+                         float* audio_out, int ld_audio, uint8_t* key_pad_out, int64_t* labels_out, m2f_stream_t stream);
+
 /* Measurement aid: one EAGER m2f_step with a hipEvent pair recorded on `stream` around every launch.  Fills, per
  * launch, kinds[] (0/1/2 = grouped GEMM forward/dgrad/wgrad form, 3/4 attention fwd/bwd, 5/6 LayerNorm fwd/bwd,
  * 7 dropout-mask, 8 criterion, 9 LayerNorm-parameter reduce), ms[] (device time) and flops[] (algorithmic FLOPs of

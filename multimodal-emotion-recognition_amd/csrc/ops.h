@@ -172,6 +172,16 @@ struct CastItem { const float* src; uint16_t* dst; int rows, cols, lds, ldd; uin
 struct CastBatch { CastItem it[M2F_CAST_MAX_ITEMS]; int count; };
 hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream);
 
+// Dialogue batcher (replaces Dataset.__getitem__ + collate_fn, reference src/dataset.py:32-89, on the device): token slot t
+// takes row rows[t] of the two device-resident embedding tables (rows[t] < 0: padded slot -> zeros, label -1, key_pad 1).
+struct GatherArgs {
+    const float* text_table; const float* audio_table; const int64_t* label_table;
+    const int32_t* rows;
+    int T, d_text, d_audio, ld_text, ld_audio;
+    float* text_out; float* audio_out; uint8_t* key_pad; int64_t* labels;
+};
+hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream);
+
 // in-place: x[t, c] *= keep(site, t*d + c) / (1 - p)
 hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
                                       uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream);

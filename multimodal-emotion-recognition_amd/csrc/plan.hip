@@ -1181,6 +1181,17 @@ int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights,
     return n;
 }
 
+int m2f_gather_dialogues(const float* text_table, int d_text, const float* audio_table, int d_audio,
+                         const int64_t* label_table, const int32_t* rows, int T, float* text_out, int ld_text,
+                         float* audio_out, int ld_audio, uint8_t* key_pad_out, int64_t* labels_out, m2f_stream_t stream) {
+    GatherArgs a;
+    a.text_table = text_table; a.audio_table = audio_table; a.label_table = label_table; a.rows = rows;
+    a.T = T; a.d_text = d_text; a.d_audio = d_audio; a.ld_text = ld_text; a.ld_audio = ld_audio;
+    a.text_out = text_out; a.audio_out = audio_out; a.key_pad = key_pad_out; a.labels = labels_out;
+    M2F_HIP(m2f_launch_gather(a, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int m2f_rng_advance(uint32_t* rng_state, m2f_stream_t stream) {
     M2F_HIP(m2f_launch_rng_advance(rng_state, static_cast<hipStream_t>(stream)));
     return 0;

@@ -336,6 +336,38 @@ __global__ __launch_bounds__(256) void m2f_cast_kernel(const CastBatch cb) {
     }
 }
 
+// one wavefront per token slot: two row copies (16-byte pieces when aligned) + label / mask
+__global__ __launch_bounds__(256) void m2f_gather_kernel(const GatherArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.T) return;
+    const int row = a.rows[t];
+    const bool pad = row < 0;
+    for (int which = 0; which < 2; ++which) {
+        const float* tab = which ? a.audio_table : a.text_table;
+        float* out = which ? a.audio_out : a.text_out;
+        const int d = which ? a.d_audio : a.d_text, ld = which ? a.ld_audio : a.ld_text;
+        if (!tab || !out) continue;
+        const float* src = tab + (size_t)(pad ? 0 : row) * d;
+        float* dst = out + (size_t)t * ld;
+        const bool vec = ((d & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(tab) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        if (vec) {
+            for (int c = 4 * lane; c < d; c += 256) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(src + c);
+                if (pad) x = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(dst + c) = x;
+            }
+        } else {
+            for (int c = lane; c < d; c += 64) dst[c] = pad ? 0.f : src[c];
+        }
+    }
+    if (lane == 0) {
+        if (a.key_pad) a.key_pad[t] = pad ? 1 : 0;
+        if (a.labels) a.labels[t] = (pad || !a.label_table) ? -1 : a.label_table[row];
+    }
+}
+
 __global__ void m2f_rng_advance_kernel(uint32_t* rng) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const uint32_t lo = rng[2] + 1u;
@@ -476,6 +508,12 @@ hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream) {
     int bx = (int)std::min<size_t>((mx + 255) / 256, 512);
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(m2f_cast_kernel, dim3(bx, cb.count), dim3(256), 0, stream, cb);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream) {
+    if (a.T < 1 || !a.rows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(m2f_gather_kernel, dim3(m2f_cdiv(a.T, 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "m2f_step": (c_int, [c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "m2f_step_timed": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_int),
                                ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double)]),
+    "m2f_gather_dialogues": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                     c_int, c_void_p, c_void_p, c_void_p]),
     "m2f_rng_advance": (c_int, [c_void_p, c_void_p]),
     "m2f_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_void_p, c_void_p]),

@@ -132,3 +132,17 @@ def test_product_path_never_imports_oracle():
     for f in ("model.py", "train.py", "test.py", "dataset.py", "utils.py"):
         src = open(os.path.join(ROOT, "src", f)).read()
         assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_dialogue_row_index_matches_dataset_semantics():
+    """Dialogues in order of first appearance, utterances sorted by Utterance_ID (reference src/dataset.py:24,35)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "src"))
+    from mer_amd.batcher import build_row_index
+    from dataset import build_dialogue_index
+    dia = [5, 5, 2, 5, 2, 9, 2]
+    utt = [1, 0, 2, 2, 0, 0, 1]
+    rows = build_row_index(dia, utt)
+    assert [r.tolist() for r in rows] == [[1, 0, 3], [4, 6, 2], [5]]
+    ids, rows2 = build_dialogue_index(dia, utt)
+    assert ids == [5, 2, 9] and [r.tolist() for r in rows2] == [r.tolist() for r in rows]

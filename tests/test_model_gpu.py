@@ -289,3 +289,43 @@ def test_state_dict_and_checkpoint_format(tmp_path):
     # a torch.optim.Adam state_dict (what reference checkpoints hold) loads too
     ref_opt = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=0.01)
     ref_opt.load_state_dict(ck["optimizer_state_dict"])
+
+
+def test_device_dialogue_batcher_equals_collate():
+    """the gather kernel must reproduce Dataset.__getitem__ + collate_fn bit for bit (it only moves data)."""
+    from mer_amd.batcher import DeviceDialogueBatcher, build_row_index
+    g = torch.Generator().manual_seed(3)
+    n_dia, d_t, d_a = 9, 72, 60
+    lens = [int(x) for x in torch.randint(1, 12, (n_dia,), generator=g)]
+    dia_ids, utt_ids = [], []
+    for d, n in enumerate(lens):
+        perm = torch.randperm(n, generator=g).tolist()          # rows of a dialogue are not stored in utterance order
+        dia_ids += [100 + d] * n
+        utt_ids += perm
+    N = len(dia_ids)
+    order = torch.randperm(N, generator=g).tolist()              # and dialogues are interleaved in the table
+    dia_ids = [dia_ids[i] for i in order]
+    utt_ids = [utt_ids[i] for i in order]
+    text, audio = torch.randn(N, d_t, generator=g), torch.randn(N, d_a, generator=g)
+    labels = torch.randint(0, 7, (N,), generator=g)
+    rows = build_row_index(dia_ids, utt_ids)
+    bat = DeviceDialogueBatcher(text, audio, labels, rows)
+    pick = [4, 0, 7, 2]
+    got = bat.gather(pick)
+    ref = O.collate([{"text": text[torch.as_tensor(rows[i])], "audio": audio[torch.as_tensor(rows[i])],
+                      "emotion": labels[torch.as_tensor(rows[i])]} for i in pick])
+    assert torch.equal(got["text"].cpu(), ref["text"]) and torch.equal(got["audio"].cpu(), ref["audio"])
+    assert torch.equal(got["emotion"].cpu(), ref["emotion"]) and torch.equal(got["padding_mask"].cpu(), ref["padding_mask"])
+    for i in pick:                                               # utterance order inside each dialogue
+        u = [utt_ids[r] for r in rows[i]]
+        assert u == sorted(u)
+    # straight into a plan's (padded-stride) staging buffers, then a train step from them
+    cfg = synth._cfg(d_a, d_t, 96, 4, 3, 2, 1, 1, 1)
+    m = _model(cfg, train=True)
+    B, L = len(pick), max(len(rows[i]) for i in pick)
+    plan = m.engine(torch.device("cuda")).plan(B, L, True, False)
+    bat.gather(pick, plan)
+    loss_a = plan.step(0.1, False, True, False)[0].item()
+    loss_b = m.train_step(ref["text"].cuda(), ref["audio"].cuda(), ref["padding_mask"].cuda(), ref["emotion"].cuda(),
+                          use_graph=False).item()
+    assert loss_a == loss_b

@@ -1,0 +1,98 @@
+"""GPU test of the drop-in driver surface (src/train.py, src/test.py, src/dataset.py): training_loop / train / validate /
+test with the reference's signatures, on a synthetic MELD-shaped dataset (the real CSVs are not in the container)."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "src"))
+
+import synth  # noqa: E402
+from oracle import m2fnet_oracle as O  # noqa: E402
+
+
+def _dataset(n_dia, d_t, d_a, seed):
+    import dataset as ds
+    g = np.random.default_rng(seed)
+    rows = []
+    for d in range(n_dia):
+        for u in range(int(g.integers(1, 10))):
+            rows.append((f"utt {d}-{u}", list(ds.EMOTIONS)[int(g.integers(0, 7))], d, u))
+    order = g.permutation(len(rows))
+    table = pd.DataFrame([rows[i] for i in order], columns=["Utterance", "Emotion", "Dialogue_ID", "Utterance_ID"])
+    text = torch.from_numpy(g.standard_normal((len(rows), d_t)).astype(np.float32))
+    audio = torch.from_numpy(g.standard_normal((len(rows), d_a)).astype(np.float32))
+    # make the label learnable from the text embedding so the loss must fall
+    lab = table["Emotion"].map(ds.EMOTIONS).to_numpy()
+    text[np.arange(len(rows)), lab] += 3.0
+    return ds.Dataset("train", text_embeddings=text, audio_embeddings=audio, table=table)
+
+
+def test_training_loop_checkpoint_validate_and_test(tmp_path, monkeypatch):
+    monkeypatch.chdir(ROOT)
+    import dataset as ds
+    import train as tr
+    import test as te
+    from utils import AttrDict, get_config
+    cfg = AttrDict(dict(get_config()))
+    model_cfg = synth._cfg(40, 48, 64, 4, 4, 4, 1, 1, 1, dropout=0.1)
+    cfg.model = AttrDict(model_cfg)
+    cfg.solver = AttrDict(dict(cfg.solver, epochs=4, lr=2e-3,
+                               early_stopping=AttrDict(enabled=True, patience=2, restore_best_weights=True),
+                               scheduler=AttrDict(enabled=True, scheduler_fn="ExponentialLR", gamma=0.9)))
+    cfg.checkpoint = AttrDict(save_path=str(tmp_path / "ck" / "m2fnet.pth"), load_path=str(tmp_path / "ck" / "m2fnet.pth"),
+                              save_checkpoint=True, load_checkpoint=False)
+    d_train, d_val = _dataset(40, 48, 40, 1), _dataset(12, 48, 40, 2)
+    dl_train = torch.utils.data.DataLoader(d_train, collate_fn=ds.collate_fn, batch_size=8, shuffle=True)
+    dl_val = torch.utils.data.DataLoader(d_val, collate_fn=ds.collate_fn, batch_size=8, shuffle=False)
+    device = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = tr.M2FNet(cfg.model).to(device)
+    crit = tr.M2FCrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)
+    opt = tr.FusedAdam(model, lr=cfg.solver.lr, weight_decay=cfg.solver.weight_decay)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+    out = tr.training_loop(model, dl_train, dl_val, crit, opt, sched, 0, cfg, device)
+    losses = out["loss_values"]
+    assert len(losses) >= 2 and losses[-1] < losses[0] - 0.2, losses
+    ck = torch.load(cfg.checkpoint.save_path)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict"}
+    assert list(ck["model_state_dict"].keys()) == list(synth.make_state_dict(model_cfg).keys())
+    assert abs(opt.param_groups[0]["lr"] - cfg.solver.lr * 0.9 ** len(losses)) < 1e-9
+
+    # validate(): per-batch metrics, unweighted mean over batches == the oracle's rule on the same logits
+    loss_v, acc, f1 = tr.validate(model, dl_val, crit, device)
+    model.eval()
+    batches = []
+    with torch.inference_mode():
+        for b in dl_val:
+            lg = model(b["text"].to(device), b["audio"].to(device), b["padding_mask"].to(device)).cpu()
+            batches.append((lg, b["emotion"]))
+    acc_o, f1_o = O.epoch_metrics(batches)
+    assert abs(acc - acc_o) < 1e-9 and abs(f1 - f1_o) < 1e-9 and np.isfinite(loss_v)
+    assert 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0
+    acc_t, f1_t = te.test(model, dl_val, device)
+    assert abs(acc_t - acc) < 1e-9 and abs(f1_t - f1) < 1e-9
+
+    # non-fused loop body (model(), criterion, backward, step) trains too
+    model2 = tr.M2FNet(cfg.model).to(device)
+    opt2 = tr.FusedAdam(model2, lr=2e-3, weight_decay=0.01)
+    monkeypatch.setattr(tr, "_fusable", lambda m, c: False)
+    l0 = tr.train(model2, dl_train, crit, opt2, 0, False, device)
+    l1 = tr.train(model2, dl_train, crit, opt2, 1, False, device)
+    assert l1 < l0
+
+
+def test_collate_fn_contract_matches_oracle():
+    import dataset as ds
+    d = _dataset(6, 16, 8, 5)
+    items = [d[i] for i in range(len(d))]
+    a, b = ds.collate_fn(items), O.collate(items)
+    for k in ("text", "audio", "padding_mask", "emotion"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["emotion"].dtype == torch.int64 and a["padding_mask"].dtype == torch.bool

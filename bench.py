@@ -141,8 +141,7 @@ def main():
 
         def one_step():
             plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
-            stepper.reducer.all_reduce()                                # RCCL sum over ranks (no-op at N=1)
-            opt.step()                                                  # fused Adam, g / global denominator
+            stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
 
         eng.publish_grads()
         for _ in range(max(args.warmup, 3)):           # >= 3: eager warm-up, graph capture, first replay

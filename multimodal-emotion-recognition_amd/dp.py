@@ -101,6 +101,17 @@ class GradReducer:
             w.wait()
         self._work = []
 
+    def reduce_and_step(self, optimizer) -> None:
+        """Pipelined exchange + update: the buckets are all-reduced LAST FIRST (the tail bucket carries the global
+        denominator every update needs), and the fused-Adam launch of bucket k only waits for bucket k's collective,
+        so the HBM-bound optimizer runs under the xGMI-bound exchange of the following buckets."""
+        if not dist.is_initialized():
+            optimizer.step()
+            return
+        order = list(reversed(self.chunks))
+        work = [dist.all_reduce(self.buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a, b in order]
+        optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
+
     @property
     def global_den(self) -> torch.Tensor:          # device scalar view, feeds m2f_adam_step(grad_scale_ptr)
         return self.buf[self.n + 1: self.n + 2]
@@ -143,9 +154,8 @@ class DataParallelStep:
             if class_weights is not None:
                 plan.class_w[: class_weights.numel()].copy_(class_weights)
             plan.step(label_smoothing, class_weights is not None, False, use_graph)   # tail <- (loss, den, num)
-            self.reducer.all_reduce()
             eng.publish_grads()
-            self.optimizer.step()
+            self.reducer.reduce_and_step(self.optimizer)
             loss = self.reducer.global_loss()
         cur.wait_stream(eng.stream)
         return loss

@@ -105,6 +105,25 @@ class FusedAdam(torch.optim.Optimizer):
                           g["weight_decay"], self.grad_scale)
         return loss
 
+    @torch.no_grad()
+    def step_ranges(self, ranges, before_each=None):
+        """One optimizer step issued as several kernel launches over contiguous element ranges [(lo, hi), ...] of the
+        flat buffers (hi clipped to the parameter count; lo, hi multiples of 4).  `before_each(i)` runs before range i
+        is launched - the data-parallel path waits there for that range's all-reduce, so the update of one bucket
+        overlaps the exchange of the next."""
+        eng = self._bind()
+        g = self.param_groups[0]
+        flat_grad = eng.ensure_grad()
+        n = eng.flat.numel()
+        self._step += 1
+        for i, (lo, hi) in enumerate(ranges):
+            if before_each is not None:
+                before_each(i)
+            hi = min(hi, n)
+            if hi > lo:
+                runtime.adam_step(eng.flat[lo:hi], flat_grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step, g["lr"],
+                                  g["betas"], g["eps"], g["weight_decay"], self.grad_scale)
+
     def state_dict(self):
         if self._engine is not None and self._step > 0:
             self._materialise_state(self._engine)

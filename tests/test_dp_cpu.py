@@ -51,6 +51,20 @@ def _worker(rank, world, port, q):
             ref = ref_grads[sp.name].reshape(-1)
             worst = max(worst, float((g[sp.offset: sp.offset + sp.numel] - ref).abs().max() / ref.abs().max().clamp_min(1e-6)))
         out.update(ref_loss=float(ref_loss), worst=worst, n_valid=int((emotion != -1).sum()))
+    # pipelined exchange + update: buckets reduced tail-first, each "optimizer" range waits only for its own bucket
+    buf2 = torch.full((1000 + dp.TAIL,), float(rank + 1))
+    red2 = dp.GradReducer(buf2, 1000, n_buckets=4)
+    seen = []
+
+    class FakeOpt:
+        def step_ranges(self, ranges, before_each=None):
+            for i, (lo, hi) in enumerate(ranges):
+                before_each(i)
+                seen.append((lo, hi, float(buf2[lo]), float(buf2[min(hi, buf2.numel()) - 1])))
+    red2.reduce_and_step(FakeOpt())
+    total = float(sum(range(1, world + 1)))
+    out["pipelined_ok"] = (all(a == total and b == total for _, _, a, b in seen) and seen[0][1] == buf2.numel()
+                           and sorted((lo, hi) for lo, hi, _, _ in seen) == sorted(red2.chunks))
     means = [torch.zeros(1) for _ in range(world)]
     dist.all_gather(means, local_mean.detach().reshape(1))
     out["mean_of_means"] = float(torch.stack(means).mean())
@@ -78,6 +92,7 @@ def test_two_rank_gloo_global_denominator():
     assert r0["worst"] < 1e-4, r0["worst"]
     assert abs(r0["mean_of_means"] - r0["ref_loss"]) > 1e-4, "ranks hold different valid counts: mean of means differs"
     assert r0["max_time"] == 2.0 and res[1]["max_time"] == 2.0
+    assert r0["pipelined_ok"] and res[1]["pipelined_ok"]
 
 
 def test_shard_dialogues_partition():

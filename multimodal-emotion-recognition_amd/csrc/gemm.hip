@@ -137,9 +137,6 @@ struct Stage {
     // Issue the loads of the tile at (kbase) of segment pointer p.  kseg = 0 marks a tile past the end (all masked).
     __device__ __forceinline__ void issue(const float* __restrict__ p, int kseg, int kbase) {
         kseg_ = kseg; kbase_ = kbase;
-#ifdef M2F_EXP_NOLOAD
-        full_ = true; return;
-#endif
         full_ = (row0_ + BR <= rows_) && (kbase + BK <= kseg);
         const float* pt = p + (RC ? (size_t)kbase * ld_ : (size_t)kbase);
         if (full_) issue_impl<true>(pt);
@@ -208,10 +205,6 @@ struct Stage {
         }
     }
     __device__ __forceinline__ void store(char* lds, bool relu, bool do_cs, f32x4& cs) {
-#ifdef M2F_EXP_NOSTORE
-        if (v[0][0] == 12345.678f) lds[threadIdx.x] = 1;     // keep the loads alive
-        return;
-#endif
         if (full_) store_impl<true>(lds, relu, do_cs, cs);
         else store_impl<false>(lds, relu, do_cs, cs);
     }
@@ -354,9 +347,6 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](int cur) {
-#ifdef M2F_EXP_NOCOMPUTE
-        return;
-#endif
         const char* a_l = ldsA + cur * SA::LDS_BYTES;
         const char* b_l = ldsB + cur * SB::LDS_BYTES;
         if constexpr (PREC == M2F_PREC_F32) {
@@ -499,46 +489,57 @@ struct Stage16KC {                       // element (row, k) at q[row*ld + k]
     static constexpr int ROWB = BK * 2 + 16, LDS_BYTES = BR * ROWB;
     static_assert(NT >= 1 && (BR * KCH) % 256 == 0, "tile split");
     uint4 v[NT];
-    int off[NT];
-    int ld_, rows_, row0_, kpad_, kbase_;
+    uint32_t off[NT];                    // BYTE offset of chunk t from the row-panel base at kbase = 0 (row clamped)
+    int rows_, row0_, kpad_, kbase_, tid_;
     bool full_;
-    __device__ __forceinline__ void setup(int ld, int rows, int row0) {
-        ld_ = ld; rows_ = rows; row0_ = row0;
+    __device__ __forceinline__ void setup(int ld, int rows, int row0, int tid) {
+        rows_ = rows; row0_ = row0; tid_ = tid;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int id = threadIdx.x + 256 * t, r = id / KCH, kc = id % KCH;
+            const int id = tid + 256 * t, r = id / KCH, kc = id % KCH;
             int gr = row0 + r;
             gr = gr < rows - 1 ? gr : rows - 1;
-            off[t] = gr * ld + 8 * kc;
+            off[t] = 2u * (uint32_t)(gr * ld + 8 * kc);
         }
+    }
+    // uniform 64-bit base + zero-extended 32-bit lane offset: the saddr form of global_load (no per-load 64-bit VALU add)
+    __device__ __forceinline__ static uint4 ld16(const char* base, uint32_t o) {
+        return *reinterpret_cast<const uint4*>(base + (size_t)o);
     }
     __device__ __forceinline__ void issue(const uint16_t* __restrict__ q, int kseg, int kbase) {
         kpad_ = (kseg + 7) & ~7; kbase_ = kbase;
         full_ = (row0_ + BR <= rows_) && (kbase + BK <= kpad_);
-        const uint16_t* pt = q + kbase;
+        const char* pt = reinterpret_cast<const char*>(q + kbase);
         if (full_) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = *reinterpret_cast<const uint4*>(pt + off[t]);
+            for (int t = 0; t < NT; ++t) v[t] = ld16(pt, off[t]);
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int kc = (threadIdx.x + 256 * t) % KCH;
-                const int o = (kbase + 8 * kc < kpad_) ? off[t] : off[t] - 8 * kc - kbase;     // else: row start
-                v[t] = *reinterpret_cast<const uint4*>(pt + o);
+                const int kc = (tid_ + 256 * t) % KCH;
+                const uint32_t o = (kbase + 8 * kc < kpad_) ? off[t] : off[t] - 16u * kc;      // else: this tile's first chunk
+                v[t] = ld16(pt, o);
             }
         }
     }
     __device__ __forceinline__ void store(char* lds, bool relu) {
+        // the rare fix-ups (edge masks, relu of the operand) sit behind ONE block-uniform branch, so the common path
+        // is eight back-to-back ds_write_b128 with progressive vmcnt waits and no control flow in between
+        if (!full_ || relu) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int id = tid_ + 256 * t, r = id / KCH, kc = id % KCH;
+                uint4 x = v[t];
+                const bool ok = full_ || ((row0_ + r < rows_) && (kbase_ + 8 * kc < kpad_));
+                if (!ok) x = make_uint4(0u, 0u, 0u, 0u);
+                if (relu) { x.x = relu_bf16x2(x.x); x.y = relu_bf16x2(x.y); x.z = relu_bf16x2(x.z); x.w = relu_bf16x2(x.w); }
+                v[t] = x;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int id = threadIdx.x + 256 * t, r = id / KCH, kc = id % KCH;
-            uint4 x = v[t];
-            if (!full_) {
-                const bool ok = (row0_ + r < rows_) && (kbase_ + 8 * kc < kpad_);
-                if (!ok) x = make_uint4(0u, 0u, 0u, 0u);
-            }
-            if (relu) { x.x = relu_bf16x2(x.x); x.y = relu_bf16x2(x.y); x.z = relu_bf16x2(x.z); x.w = relu_bf16x2(x.w); }
-            *reinterpret_cast<uint4*>(lds + r * ROWB + kc * 16) = x;
+            const int id = tid_ + 256 * t, r = id / KCH, kc = id % KCH;
+            *reinterpret_cast<uint4*>(lds + r * ROWB + kc * 16) = v[t];
         }
     }
 };
@@ -624,8 +625,15 @@ __device__ __forceinline__ bf16x8 frag_from_kmajor(const char* img, int rowk, in
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// Workgroup = 8 waves in two ROLES (wave-specialised): waves 0-3 are CONSUMERS (LDS fragments -> MFMA -> epilogue,
+// 2x2 over the tile), waves 4-7 are PRODUCERS (global -> registers, D k-tiles in flight -> LDS image).  With one
+// workgroup per CU - all these small-M launches offer - a SIMD then holds one wave of each role, so the address
+// arithmetic / ds_write stream of tile k+1 issues in the shadow of the ds_read + MFMA run of tile k instead of in front
+// of it (measured before the split: 0.62 us per 128-wide k-tile, ~40 % of it instruction issue of one wave per SIMD,
+// MFMA busy 13 %).  The two roles run separate loops with the same barrier count, so their register sets (the load ring
+// vs accumulators + fragments) overlap in the allocation instead of adding up.
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
-__global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
+__device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     static_assert(!(A_RC && !B_RC), "layouts: NT, NN, TN");
     constexpr bool TN = A_RC && B_RC;
     static_assert(!TN || BM == BN, "the TN stager shares one patch shape for both operands");
@@ -639,8 +647,8 @@ __global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
     constexpr int U = (D % 2 == 0) ? D : 2 * D;                 // unroll so that set and LDS-buffer indices are static
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const bool producer = threadIdx.x >= 256;                   // wave-uniform
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
     const int bpos = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int pi = 0;
 #pragma unroll
@@ -651,58 +659,102 @@ __global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
     const int tl = bpos - P.tile_begin;
     const int tiles_m = (M + BM - 1) / BM;
     const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;       // M fastest: neighbours share the B panel
-    const uint32_t flags = P.flags;
-    const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
     const int nk0 = (P.a.k[0] + BK - 1) / BK, nk = nk0 + (P.a.k[1] + BK - 1) / BK;
     char* ldsA = smem;
     char* ldsB = smem + 2 * LDS_A;
+    const bool has_bg = TN && P.bias_grad != nullptr && n0 == 0;        // block-uniform
+    float* red = reinterpret_cast<float*>(smem);                        // bias-grad partials (after the k-loop)
+    constexpr int KP = BK / 8, RP = BM / 8;
 
-    // one register set = this thread's share of one k-tile of both operands
-    struct Set {
-        SAK ak;            // NT, NN: A
-        SBK bk;            // NT: B
-        SBR br;            // NN: B (threads 0..127) | TN: A (threads 0..127) or B (threads 128..255)
-    };
-    Set sets[D];
-    int cur_seg = -1;
-    const bool second_half = tid >= 128;
-    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool want_bg = TN && P.bias_grad != nullptr && n0 == 0 && !second_half;
-
-    auto setup_all = [&](int seg) {
+    if (producer) {
+        // ================================ PRODUCER: global -> registers -> LDS ================================
+        const uint32_t flags = P.flags;
+        const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
+        struct Set {                   // one register set = this thread's share of one k-tile of both operands
+            SAK ak;                    // NT, NN: A
+            SBK bk;                    // NT: B
+            SBR br;                    // NN: B (threads 0..127) | TN: A (threads 0..127) or B (threads 128..255)
+        };
+        Set sets[D];
+        int cur_seg = -1;
+        const bool second_half = tid >= 128;
+        float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool want_bg = has_bg && !second_half;
+        // operand descriptors in SGPRs for the whole k-loop: indexing P.a.q[seg] with a run-time seg makes the compiler
+        // re-read the kernarg segment (s_load + lgkmcnt(0)) several times per k-tile, serialised in front of the loads
+        const uint16_t* const aq0 = P.a.q[0]; const uint16_t* const aq1 = P.a.q[1];
+        const uint16_t* const bq0 = P.b.q[0]; const uint16_t* const bq1 = P.b.q[1];
+        const int ak0 = P.a.k[0], ak1 = P.a.k[1];
+        const int ald0 = P.a.ldq[0], ald1 = P.a.ldq[1], bld0 = P.b.ldq[0], bld1 = P.b.ldq[1];
+        auto setup_all = [&](int seg) {
+            const int lda = seg ? ald1 : ald0, ldb = seg ? bld1 : bld0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            if constexpr (!A_RC) sets[i].ak.setup(P.a.ldq[seg], M, m0);
-            if constexpr (!B_RC) sets[i].bk.setup(P.b.ldq[seg], N, n0);
-            if constexpr (!A_RC && B_RC) sets[i].br.setup(P.b.ldq[seg], N, n0, tid);
+            for (int i = 0; i < D; ++i) {
+                if constexpr (!A_RC) sets[i].ak.setup(lda, M, m0, tid);
+                if constexpr (!B_RC) sets[i].bk.setup(ldb, N, n0, tid);
+                if constexpr (!A_RC && B_RC) sets[i].br.setup(ldb, N, n0, tid);
+                if constexpr (TN) {
+                    if (second_half) sets[i].br.setup(ldb, N, n0, tid - 128);
+                    else sets[i].br.setup(lda, M, m0, tid);
+                }
+            }
+        };
+        auto issue = [&](Set& st, int kt_raw) {                 // unconditional: past-the-end tiles are fully masked
+            const bool tv = kt_raw < nk;
+            const int kt = tv ? kt_raw : 0;
+            const int seg = kt >= nk0 ? 1 : 0;
+            const int kbase = (seg ? kt - nk0 : kt) * BK;
+            if (seg != cur_seg) { setup_all(seg); cur_seg = seg; }   // wave-uniform, at most twice
+            const int ks = tv ? (seg ? ak1 : ak0) : 0;
+            const uint16_t* const qa = seg ? aq1 : aq0;
+            const uint16_t* const qb = seg ? bq1 : bq0;
+            if constexpr (!A_RC) st.ak.issue(qa, ks, kbase);
+            if constexpr (!B_RC) st.bk.issue(qb, ks, kbase);
+            if constexpr (!A_RC && B_RC) st.br.issue(qb, ks, kbase);
+            if constexpr (TN) st.br.issue(second_half ? qb : qa, ks, kbase);
+        };
+        auto store = [&](Set& st, int buf) {
+            if constexpr (!A_RC) st.ak.store(ldsA + buf * LDS_A, reluA);
+            if constexpr (!B_RC) st.bk.store(ldsB + buf * LDS_B, reluB);
+            if constexpr (!A_RC && B_RC) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
             if constexpr (TN) {
-                if (second_half) sets[i].br.setup(P.b.ldq[seg], N, n0, tid - 128);
-                else sets[i].br.setup(P.a.ldq[seg], M, m0, tid);
+                if (second_half) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
+                else st.br.store(ldsA + buf * LDS_A, reluA, want_bg, colsum);
+            }
+        };
+
+#pragma unroll
+        for (int i = 0; i < D; ++i) issue(sets[i], i);
+        store(sets[0], 0);
+        lds_barrier();                                          // (B0) tile 0 visible
+        issue(sets[0], D);
+        for (int kt0 = 0; kt0 < nk; kt0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kt = kt0 + u;
+                if (kt < nk) {                                   // block-uniform
+                    store(sets[(u + 1) % D], (u + 1) & 1);       // tile kt+1 (all-zero past the end) while tile kt is multiplied
+                    lds_barrier();                               // (B1 per tile)
+                    issue(sets[(u + 1) % D], kt + 1 + D);
+                }
             }
         }
-    };
-    auto issue = [&](Set& st, int kt_raw) {                     // unconditional: past-the-end tiles are fully masked
-        const bool tv = kt_raw < nk;
-        const int kt = tv ? kt_raw : 0;
-        const int seg = kt >= nk0 ? 1 : 0;
-        const int kbase = (seg ? kt - nk0 : kt) * BK;
-        if (seg != cur_seg) { setup_all(seg); cur_seg = seg; }   // wave-uniform, at most twice
-        const int ks = tv ? P.a.k[seg] : 0;
-        if constexpr (!A_RC) st.ak.issue(P.a.q[seg], ks, kbase);
-        if constexpr (!B_RC) st.bk.issue(P.b.q[seg], ks, kbase);
-        if constexpr (!A_RC && B_RC) st.br.issue(P.b.q[seg], ks, kbase);
-        if constexpr (TN) st.br.issue(second_half ? P.b.q[seg] : P.a.q[seg], ks, kbase);
-    };
-    auto store = [&](Set& st, int buf) {
-        if constexpr (!A_RC) st.ak.store(ldsA + buf * LDS_A, reluA);
-        if constexpr (!B_RC) st.bk.store(ldsB + buf * LDS_B, reluB);
-        if constexpr (!A_RC && B_RC) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
         if constexpr (TN) {
-            if (second_half) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
-            else st.br.store(ldsA + buf * LDS_A, reluA, want_bg, colsum);
+            if (has_bg) {
+                // threads 0..127 hold column sums of their 8 rows over their k-group: red[kp][row], then fixed-order sum
+                if (!second_half) {
+                    const int kp = tid / RP, rp = tid % RP;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[kp * BM + 8 * rp + e] = colsum[e];
+                }
+                lds_barrier();                                   // (B2)
+            }
         }
-    };
+        return;                                                 // every issued load was consumed or is dead: nothing to drain
+    }
 
+    // ==================================== CONSUMER: LDS -> MFMA -> epilogue ====================================
+    const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -716,57 +768,46 @@ __global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
         const char* bimg = ldsB + buf * LDS_B;
         const char* ab = aimg + (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;      // row-major images
         const char* bb = bimg + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+        // all fragments of the k-tile first (one exposed LDS latency per tile instead of one per 16-wide k-slice), then
+        // the MFMA run back to back
+        constexpr int KS = BK / 16;
+        bf16x8 a[KS][MI], b[KS][NI];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[MI], b[NI];
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                if constexpr (A_RC) a[i] = frag_from_kmajor(aimg, ROWK, wm * (BM / 2) + i * 32, 16 * ks, lane);
-                else a[i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * ROWB + ks * 32);
+                if constexpr (A_RC) a[ks][i] = frag_from_kmajor(aimg, ROWK, wm * (BM / 2) + i * 32, 16 * ks, lane);
+                else a[ks][i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * ROWB + ks * 32);
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                if constexpr (B_RC) b[j] = frag_from_kmajor(bimg, ROWK, wn * (BN / 2) + j * 32, 16 * ks, lane);
-                else b[j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * ROWB + ks * 32);
+                if constexpr (B_RC) b[ks][j] = frag_from_kmajor(bimg, ROWK, wn * (BN / 2) + j * 32, 16 * ks, lane);
+                else b[ks][j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * ROWB + ks * 32);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the reads ahead of the MFMA run (the scheduler sinks them otherwise)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     };
 
-#pragma unroll
-    for (int i = 0; i < D; ++i) issue(sets[i], i);
-    store(sets[0], 0);
-    lds_barrier();
-    issue(sets[0], D);
-
+    lds_barrier();                                              // (B0)
     for (int kt0 = 0; kt0 < nk; kt0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kt = kt0 + u;
-            if (kt < nk) {                                       // block-uniform
+            if (kt0 + u < nk) {                                  // block-uniform
                 compute(u & 1);
-                store(sets[(u + 1) % D], (u + 1) & 1);           // tile kt+1 (all-zero past the end)
-                lds_barrier();
-                issue(sets[(u + 1) % D], kt + 1 + D);
+                lds_barrier();                                   // (B1 per tile)
             }
         }
     }
-
     if constexpr (TN) {
-        if (P.bias_grad != nullptr && n0 == 0) {                 // block-uniform
-            // threads 0..127 hold column sums of their 8 rows over their k-group: red[kp][row], then fixed-order sum
-            float* red = reinterpret_cast<float*>(smem);
-            constexpr int KP = BK / 8, RP = BM / 8;
-            if (!second_half) {
-                const int kp = tid / RP, rp = tid % RP;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) red[kp * BM + 8 * rp + e] = colsum[e];
-            }
-            __syncthreads();
+        if (has_bg) {
+            lds_barrier();                                       // (B2) producers' partial sums are in LDS
             if (tid < BM) {
                 float sum = 0.f;
                 for (int q = 0; q < KP; ++q) sum += red[q * BM + tid];
@@ -777,12 +818,27 @@ __global__ __launch_bounds__(256) void m2f_gemm16_kernel(const GemmBatch gb) {
     gemm_epilogue<MI, NI, BM, BN>(gb, P, acc, m0, n0, lane, wm, wn);
 }
 
+// Two register budgets of the same body.  "wide": up to 256 VGPRs, one workgroup (8 waves) per CU - the launches with
+// at most one tile per CU, where a deep load ring is what matters.  "dense": at most 128 VGPRs (4 waves per SIMD), two
+// workgroups per CU with a shallower ring each - the launches with more tiles than CUs.
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(512) void m2f_gemm16_kernel(const GemmBatch gb) {
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D>(gb);
+}
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void m2f_gemm16_dense_kernel(const GemmBatch gb) {
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D>(gb);
+}
+
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false>
 hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
     constexpr int lds = 2 * (A_RC ? Stage16RC<BM, BK>::LDS_BYTES : Stage16KC<BM, BK>::LDS_BYTES) +
                         2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D>;
+    static_assert(!DENSE || 2 * lds <= 160 * 1024, "two workgroups per CU");
+    void (*kern)(const GemmBatch);
+    if constexpr (DENSE) kern = m2f_gemm16_dense_kernel<A_RC, B_RC, BM, BN, BK, D>;
+    else kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -791,7 +847,7 @@ hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(256), lds, stream, gb);
+    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds, stream, gb);
     return hipGetLastError();
 }
 
@@ -894,6 +950,7 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
     constexpr int D64 = (!A_RC && B_RC) ? 3 : 4;     // dgrad holds a 32-register patch per set -> one stage less
     if (tile == 128) return launch_cfg16<A_RC, B_RC, 128, 128, 64, 3>(gb, t, stream);
     // (a 6-deep variant that keeps the whole K = 768 in flight was measured: no gain over 4)
+    if (t > 256) return launch_cfg16<A_RC, B_RC, 64, 64, 128, 2, true>(gb, t, stream);      // two workgroups per CU
     return launch_cfg16<A_RC, B_RC, 64, 64, 128, D64>(gb, t, stream);
 }
 

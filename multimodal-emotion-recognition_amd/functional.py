@@ -45,8 +45,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: int = NT, precision: int = ru
          res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0,
          bias_grad: bool = False, relu_a: bool = False, relu_b: bool = False, relu_out: bool = False,
          out: Optional[torch.Tensor] = None, accumulate: bool = False, drop_site: int = 0, drop_p: float = 0.0,
-         rng: Optional[torch.Tensor] = None, tile: int = 0, split_k: bool = False, src16: bool = False):
-    """layout NT: a[M,K] b[N,K]; NN: a[M,K] b[K,N]; TN: a[K,M] b[K,N].  Returns C (and bias_grad[M] for TN)."""
+         rng: Optional[torch.Tensor] = None, tile: int = 0, split_k: bool = False, src16: bool = False,
+         shadows=None):
+    """layout NT: a[M,K] b[N,K]; NN: a[M,K] b[K,N]; TN: a[K,M] b[K,N].  Returns C (and bias_grad[M] for TN).
+    `shadows` = prebuilt bf16 images (a, a1, b, b1) replacing the per-call ones `src16=True` makes."""
     runtime.require_gpu()
     if layout == NT:
         M, K0 = a.shape; N = b.shape[0]
@@ -61,7 +63,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: int = NT, precision: int = ru
     bg = torch.empty(M, dtype=torch.float32, device=a.device) if bias_grad else None
     ws, tickets, nmax = _splitk_scratch(a.device) if split_k else (None, None, 0)
     # bf16 shadows (test plumbing: in the plan the producer kernels write them): zero-padded to a multiple of 8 columns
-    sh = [None if (t is None or not src16) else _shadow16(t) for t in (a, a1, b, b1)]
+    sh = list(shadows) if shadows is not None else [None if (t is None or not src16) else _shadow16(t) for t in (a, a1, b, b1)]
     shp = [(ptr(t), t.stride(0)) if t is not None else (None, 0) for t in sh]
     check(lib().m2f_gemm(precision, layout, M, N, K0, K1, ptr(a), _ld(a), ptr(a1), _ld(a1) if a1 is not None else 0,
                          ptr(b), _ld(b), ptr(b1), _ld(b1) if b1 is not None else 0, ptr(c), _ld(c), ptr(bias),

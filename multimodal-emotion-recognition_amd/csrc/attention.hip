@@ -5,64 +5,95 @@
 //   * FusionAttentionModule   (src/model.py:14: query = text, key = audio, value = text)
 // with key_padding_mask semantics (-inf on padded keys before the softmax).
 //
-// One wavefront owns one (dialogue, head): the sequence is the utterances of a dialogue (L <= 64), so
-// the whole L x L problem fits one wave.  Q/K/V (and dO in backward) tiles of the head are staged in LDS
-// (row stride = 2 mod 4 floats -> conflict-free MFMA fragment reads), QK^T and PV run on the exact-fp32
-// MFMA v_mfma_f32_16x16x4_f32, the softmax runs in registers with wavefront shuffles.  S^T = K Q^T is
-// computed so the probability tile is already laid out as the A operand of the PV product (accumulator
-// as next operand, no LDS round trip).  The backward pass evaluates dS in both orientations (cheap at
-// these sizes) so dQ and dK/dV need no transposes and no atomics.
+// One workgroup of four wavefronts owns one (dialogue, head): the sequence is the utterances of a dialogue
+// (L <= 64), so the whole L x L problem fits one wave's registers.  Q/K/V (and dO, O in backward) tiles of
+// the head are staged in LDS by all 256 threads (row stride = 2 mod 4 floats -> conflict-free MFMA fragment
+// reads; every operand is in flight before the first one is committed, so the fetch costs one memory round
+// trip), QK^T and PV run on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32, the softmax runs in registers with
+// wavefront shuffles.  S^T = K Q^T is computed so the probability tile is already laid out as the A operand of
+// the PV product (accumulator as next operand, no LDS round trip).  Every wave evaluates the (tiny) score /
+// dS tiles itself and the waves split the 16-column output tiles of O / dQ / dK / dV between them: the kernel
+// is a chain of latencies (it sits in the dependent chain of the training step), so the work of one problem is
+// spread over 4 SIMDs instead of being queued on one.  The backward pass evaluates dS in both orientations
+// (cheap at these sizes) so dQ and dK/dV need no transposes and no atomics.
 #include "common.h"
 #include "ops.h"
 
 namespace {
 
-// [Lp x W] zero-padded LDS copy of src rows [0, L) x cols [0, hd).  Loads are UNCONDITIONAL (clamped address +
-// select) and issued in batches of up to 8 per lane before any LDS write, so a slab costs about one memory round
-// trip instead of one per 16-byte piece (guarded loads compile to branch + s_waitcnt vmcnt(0) each).
+constexpr int NTHR = 256;          // 4 wavefronts per (dialogue, head)
+constexpr int NWAVE = NTHR / 64;
+
+// [Lp x W] zero-padded LDS copy of src rows [0, L) x cols [0, hd), generic form (any size / alignment).  Loads are
+// UNCONDITIONAL (clamped address + select) and issued in batches before any LDS write (guarded loads compile to
+// branch + s_waitcnt vmcnt(0) each).
 __device__ __forceinline__ void load_slab(float* __restrict__ lds, int ld, int Lp, int W,
-                                          const float* __restrict__ src, int ldg, int L, int hd,
-                                          int lane) {
-    const bool vec = ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    if (vec) {
-        const int C4 = W >> 2, total = Lp * C4;
-        for (int base = 0; base < total; base += 64 * 8) {
-            f32x4 x[8];
+                                          const float* __restrict__ src, int ldg, int L, int hd, int tid) {
+    const int total = Lp * W;
+    for (int base = 0; base < total; base += NTHR * 8) {
+        float x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + lane + 64 * u;
-                const int r = e / C4, c = (e - r * C4) << 2;
-                const bool ok = e < total && r < L && c < hd;
-                x[u] = *reinterpret_cast<const f32x4*>(src + (ok ? (size_t)r * ldg + c : (size_t)0));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + lane + 64 * u;
-                const int r = e / C4, c = (e - r * C4) << 2;
-                if (e < total) {
-                    const bool ok = r < L && c < hd;
-                    float* d = lds + r * ld + c;
-                    d[0] = ok ? x[u][0] : 0.f; d[1] = ok ? x[u][1] : 0.f; d[2] = ok ? x[u][2] : 0.f; d[3] = ok ? x[u][3] : 0.f;
-                }
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + tid + NTHR * u;
+            const int r = e / W, c = e - r * W;
+            const bool ok = e < total && r < L && c < hd;
+            x[u] = src[ok ? (size_t)r * ldg + c : (size_t)0];
         }
-    } else {
-        const int total = Lp * W;
-        for (int base = 0; base < total; base += 64 * 8) {
-            float x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + lane + 64 * u;
-                const int r = e / W, c = e - r * W;
-                const bool ok = e < total && r < L && c < hd;
-                x[u] = src[ok ? (size_t)r * ldg + c : (size_t)0];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + tid + NTHR * u;
+            const int r = e / W, c = e - r * W;
+            if (e < total) lds[r * ld + c] = (r < L && c < hd) ? x[u] : 0.f;
+        }
+    }
+}
+
+// Fast form for slabs of at most NTHR*4 float4 whose rows are 16-byte aligned: the (row, column) of each of a thread's
+// (up to) four float4 is worked out ONCE (one integer division) and shared by every slab of the kernel (same L, hd, W),
+// all slabs are issued before the first is committed.
+struct SlabGeom {
+    int goff_rc[4];      // r * 65536 + c   (r < 64, c < 256)
+    int loff[4];         // r * ld + c  (LDS float offset)
+    bool inb[4];         // element index < total (a slot of this thread exists)
+    bool ok[4];          // ... and lies inside [0, L) x [0, hd)
+};
+__device__ __forceinline__ void slab_geom(SlabGeom& G, int L, int hd, int Lp, int W, int ld, int tid) {
+    const int C4 = W >> 2, total = Lp * C4;
+    int r = tid / C4, c4 = tid - r * C4;
+    const int dr = NTHR / C4, dc = NTHR - dr * C4;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + lane + 64 * u;
-                const int r = e / W, c = e - r * W;
-                if (e < total) lds[r * ld + c] = (r < L && c < hd) ? x[u] : 0.f;
-            }
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + NTHR * u;
+        const int c = c4 << 2;
+        G.inb[u] = e < total;
+        G.ok[u] = G.inb[u] && r < L && c < hd;
+        G.goff_rc[u] = (r << 16) | c;
+        G.loff[u] = r * ld + c;
+        r += dr; c4 += dc;
+        if (c4 >= C4) { c4 -= C4; ++r; }
+    }
+}
+__device__ __forceinline__ bool slab_fast_ok(const float* src, int ldg, int hd, int Lp, int W) {
+    return ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (Lp * (W >> 2) <= NTHR * 4);
+}
+struct SlabRegs { f32x4 x[4]; };
+__device__ __forceinline__ void slab_issue(SlabRegs& R, const SlabGeom& G, const float* __restrict__ src, int ldg) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = G.goff_rc[u] >> 16, c = G.goff_rc[u] & 0xFFFF;
+        const uint32_t o = G.ok[u] ? (uint32_t)(r * ldg + c) * 4u : 0u;
+        R.x[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src) + (size_t)o);
+    }
+}
+__device__ __forceinline__ void slab_commit(const SlabRegs& R, const SlabGeom& G, float* __restrict__ lds) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (G.inb[u]) {
+            const bool ok = G.ok[u];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2* d = reinterpret_cast<f32x2*>(lds + G.loff[u]);          // r*(W+2) + c is even: 8-byte aligned
+            d[0] = f32x2{ok ? R.x[u][0] : 0.f, ok ? R.x[u][1] : 0.f};
+            d[1] = f32x2{ok ? R.x[u][2] : 0.f, ok ? R.x[u][3] : 0.f};
         }
     }
 }
@@ -72,9 +103,9 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
+__global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_ATTN_MAX_PROBLEMS; ++i)
@@ -89,10 +120,26 @@ __global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
     float* Ks = Qs + Lp * ld;
     float* Vs = Ks + Lp * ld;
     const size_t tok0 = (size_t)b * L;
-    load_slab(Qs, ld, Lp, W, P.q + tok0 * P.ldq + h * hd, P.ldq, L, hd, lane);
-    load_slab(Ks, ld, Lp, W, P.k + tok0 * P.ldk + h * hd, P.ldk, L, hd, lane);
-    load_slab(Vs, ld, Lp, W, P.v + tok0 * P.ldv + h * hd, P.ldv, L, hd, lane);
-    const unsigned long long kvalid = __ballot(lane < L && ab.key_pad[tok0 + (lane < L ? lane : 0)] == 0);
+    const float* qg = P.q + tok0 * P.ldq + h * hd;
+    const float* kg = P.k + tok0 * P.ldk + h * hd;
+    const float* vg = P.v + tok0 * P.ldv + h * hd;
+    const unsigned char kpad = ab.key_pad[tok0 + (lane < L ? lane : 0)];
+    if (slab_fast_ok(qg, P.ldq, hd, Lp, W) && slab_fast_ok(kg, P.ldk, hd, Lp, W) && slab_fast_ok(vg, P.ldv, hd, Lp, W)) {
+        SlabGeom G;
+        slab_geom(G, L, hd, Lp, W, ld, tid);
+        SlabRegs rq, rk, rv;                                  // one round trip for the three operands
+        slab_issue(rq, G, qg, P.ldq);
+        slab_issue(rk, G, kg, P.ldk);
+        slab_issue(rv, G, vg, P.ldv);
+        slab_commit(rq, G, Qs);
+        slab_commit(rk, G, Ks);
+        slab_commit(rv, G, Vs);
+    } else {
+        load_slab(Qs, ld, Lp, W, qg, P.ldq, L, hd, tid);
+        load_slab(Ks, ld, Lp, W, kg, P.ldk, L, hd, tid);
+        load_slab(Vs, ld, Lp, W, vg, P.ldv, L, hd, tid);
+    }
+    const unsigned long long kvalid = __ballot(lane < L && kpad == 0);
     __syncthreads();
 
     const float scale = 1.0f / sqrtf((float)hd);
@@ -110,11 +157,17 @@ __global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
         const int i = 16 * it + l15;                        // this lane's query row
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // two interleaved accumulators: the 16x16x4 MFMA has a 40-cycle dependent latency at an 8..32-cycle issue
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* kp = Ks + (16 * jt + l15) * ld + lg;
             const float* qp = Qs + i * ld + lg;
-            for (int ks = 0; ks < ksteps; ++ks) acc = mfma4(kp[4 * ks], qp[4 * ks], acc);
-            s[jt] = acc;                                    // S[i][j = 16jt + 4lg + r]
+            int ks = 0;
+            for (; ks + 1 < ksteps; ks += 2) {
+                acc0 = mfma4(kp[4 * ks], qp[4 * ks], acc0);
+                acc1 = mfma4(kp[4 * ks + 4], qp[4 * ks + 4], acc1);
+            }
+            if (ks < ksteps) acc0 = mfma4(kp[4 * ks], qp[4 * ks], acc0);
+            s[jt] = acc0 + acc1;                            // S[i][j = 16jt + 4lg + r]
         }
         float m = -INFINITY;
 #pragma unroll
@@ -146,12 +199,12 @@ __global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * lg + r;
                 float p = s[jt][r] * inv;
-                probs[(size_t)j * Lp + i] = p;              // P^T, pre-dropout (lanes: consecutive i)
+                if (wv == 0) probs[(size_t)j * Lp + i] = p;  // P^T, pre-dropout (lanes: consecutive i); one wave writes it
                 if (site) p = m2f_keep(key, (uint32_t)((bh * L + i) * L + j), ab.drop_thresh) ? p * ab.drop_scale : 0.f;
                 s[jt][r] = p;
             }
-        // O[i][c] = sum_j P[i][j] V[j][c]
-        for (int ct = 0; ct < (W >> 4); ++ct) {
+        // O[i][c] = sum_j P[i][j] V[j][c]; the 16-column tiles are dealt to the four waves
+        for (int ct = wv; ct < (W >> 4); ct += NWAVE) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
@@ -174,9 +227,9 @@ __global__ __launch_bounds__(64) void m2f_attn_fwd_kernel(const AttnBatch ab) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
+__global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_ATTN_MAX_PROBLEMS; ++i)
@@ -191,35 +244,73 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
     float* Ks = Qs + Lp * ld;
     float* Vs = Ks + Lp * ld;
     float* Gs = Vs + Lp * ld;          // dO
-    float* delta = Gs + Lp * ld;       // [Lp]
+    float* Os = Gs + Lp * ld;          // O (one-round-trip path only: present when ab.bwd_fast)
+    float* delta = Os + (ab.bwd_fast ? Lp * ld : 0);       // [Lp]
     const size_t tok0 = (size_t)b * L;
-    load_slab(Qs, ld, Lp, W, P.q + tok0 * P.ldq + h * hd, P.ldq, L, hd, lane);
-    load_slab(Ks, ld, Lp, W, P.k + tok0 * P.ldk + h * hd, P.ldk, L, hd, lane);
-    load_slab(Vs, ld, Lp, W, P.v + tok0 * P.ldv + h * hd, P.ldv, L, hd, lane);
-    load_slab(Gs, ld, Lp, W, P.dout + tok0 * P.lddo + h * hd, P.lddo, L, hd, lane);
+    const float* qg = P.q + tok0 * P.ldq + h * hd;
+    const float* kg = P.k + tok0 * P.ldk + h * hd;
+    const float* vg = P.v + tok0 * P.ldv + h * hd;
+    const float* gg = P.dout + tok0 * P.lddo + h * hd;
+    const float* og = P.out + tok0 * P.ldo + h * hd;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const float* probs = P.probs + (size_t)bh * Lp * Lp;
+    // NT == 1: the saved probabilities this lane needs in both orientations, fetched with everything else
+    float px[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 py = {0.f, 0.f, 0.f, 0.f};
+    const bool fast = ab.bwd_fast && slab_fast_ok(qg, P.ldq, hd, Lp, W) && slab_fast_ok(kg, P.ldk, hd, Lp, W) &&
+                      slab_fast_ok(vg, P.ldv, hd, Lp, W) && slab_fast_ok(gg, P.lddo, hd, Lp, W) && slab_fast_ok(og, P.ldo, hd, Lp, W);
+    if (fast) {
+        SlabGeom G;
+        slab_geom(G, L, hd, Lp, W, ld, tid);
+        SlabRegs rq, rk, rv, rg, ro;                          // one round trip for all five operands (+ the probabilities)
+        slab_issue(rg, G, gg, P.lddo);
+        slab_issue(ro, G, og, P.ldo);
+        slab_issue(rv, G, vg, P.ldv);
+        slab_issue(rk, G, kg, P.ldk);
+        slab_issue(rq, G, qg, P.ldq);
+        if constexpr (NT == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) px[r] = probs[(size_t)(4 * lg + r) * Lp + l15];
+            py = *reinterpret_cast<const f32x4*>(probs + (size_t)l15 * Lp + 4 * lg);
+        }
+        slab_commit(rg, G, Gs);
+        slab_commit(ro, G, Os);
+        slab_commit(rv, G, Vs);
+        slab_commit(rk, G, Ks);
+        slab_commit(rq, G, Qs);
+    } else {
+        load_slab(Qs, ld, Lp, W, qg, P.ldq, L, hd, tid);
+        load_slab(Ks, ld, Lp, W, kg, P.ldk, L, hd, tid);
+        load_slab(Vs, ld, Lp, W, vg, P.ldv, L, hd, tid);
+        load_slab(Gs, ld, Lp, W, gg, P.lddo, L, hd, tid);
+        if constexpr (NT == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) px[r] = probs[(size_t)(4 * lg + r) * Lp + l15];
+            py = *reinterpret_cast<const f32x4*>(probs + (size_t)l15 * Lp + 4 * lg);
+        }
+    }
     __syncthreads();
     // delta_i = sum_c dO[i][c] * O[i][c]  (= sum_j P[i][j] dP[i][j], also under dropout).  Four lanes per row, each
-    // streams a quarter of the row of O from global memory (unconditional clamped loads), shuffle-reduce over the 4.
-    for (int r0 = 0; r0 < Lp; r0 += 16) {
-        const int row = r0 + (lane >> 2), part = lane & 3;
-        const bool rok = row < L;
-        const float* o = P.out + (tok0 + (rok ? row : 0)) * P.ldo + h * hd;
-        const float* g = Gs + row * ld;
+    // takes a quarter of the row (O from its LDS slab, or streamed from global memory on the slow path), shuffle-reduce.
+    for (int r0 = 0; r0 < Lp; r0 += NTHR / 4) {
+        const int row = r0 + (tid >> 2), part = tid & 3;
+        const bool rin = row < Lp, rok = row < L;
+        const int rowc = rin ? row : 0;
+        const float* o = fast ? Os + rowc * ld : og + (size_t)(rok ? row : 0) * P.ldo;
+        const float* g = Gs + rowc * ld;
         float d = 0.f;
         for (int c = part; c < hd; c += 4) d += g[c] * o[c];
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
-        if (part == 0) delta[row] = rok ? d : 0.f;
+        if (part == 0 && rin) delta[row] = rok ? d : 0.f;
     }
     __syncthreads();
 
     const float scale = 1.0f / sqrtf((float)hd);
-    const int l15 = lane & 15, lg = lane >> 4;
     const int ksteps = (hd + 3) >> 2;
     const uint32_t site = P.drop_site;
     uint32_t key = 0;
     if (site) key = m2f_site_key(ab.rng, site);
-    const float* probs = P.probs + (size_t)bh * Lp * Lp;
     uint16_t* dq16 = m2f_shadow_of(ab.sh, P.dq);
     uint16_t* dk16 = m2f_shadow_of(ab.sh, P.dk);
     uint16_t* dv16 = m2f_shadow_of(ab.sh, P.dv);
@@ -232,20 +323,26 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
         const float dl = delta[i];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* vp = Vs + (16 * jt + l15) * ld + lg;
             const float* gp = Gs + i * ld + lg;
-            for (int ks = 0; ks < ksteps; ++ks) acc = mfma4(vp[4 * ks], gp[4 * ks], acc);   // dP[i][j]
+            int ks = 0;
+            for (; ks + 1 < ksteps; ks += 2) {
+                acc0 = mfma4(vp[4 * ks], gp[4 * ks], acc0);
+                acc1 = mfma4(vp[4 * ks + 4], gp[4 * ks + 4], acc1);
+            }
+            if (ks < ksteps) acc0 = mfma4(vp[4 * ks], gp[4 * ks], acc0);
+            const f32x4 acc = acc0 + acc1;                  // dP[i][j]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * lg + r;
-                const float p = probs[(size_t)j * Lp + i];
+                const float p = (NT == 1) ? px[r] : probs[(size_t)j * Lp + i];
                 float dp = acc[r];
                 if (site) dp = m2f_keep(key, (uint32_t)((bh * L + i) * L + j), ab.drop_thresh) ? dp * ab.drop_scale : 0.f;
                 ds[jt][r] = p * (dp - dl) * scale;
             }
         }
-        for (int ct = 0; ct < (W >> 4); ++ct) {
+        for (int ct = wv; ct < (W >> 4); ct += NWAVE) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
@@ -273,11 +370,17 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
         const int j = 16 * jt + l15;
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* gp = Gs + (16 * it + l15) * ld + lg;
             const float* vp = Vs + j * ld + lg;
-            for (int ks = 0; ks < ksteps; ++ks) acc = mfma4(gp[4 * ks], vp[4 * ks], acc);   // dP[i][j]
-            const f32x4 p4 = *reinterpret_cast<const f32x4*>(probs + (size_t)j * Lp + 16 * it + 4 * lg);
+            int ks = 0;
+            for (; ks + 1 < ksteps; ks += 2) {
+                acc0 = mfma4(gp[4 * ks], vp[4 * ks], acc0);
+                acc1 = mfma4(gp[4 * ks + 4], vp[4 * ks + 4], acc1);
+            }
+            if (ks < ksteps) acc0 = mfma4(gp[4 * ks], vp[4 * ks], acc0);
+            const f32x4 acc = acc0 + acc1;                  // dP[i][j]
+            const f32x4 p4 = (NT == 1) ? py : *reinterpret_cast<const f32x4*>(probs + (size_t)j * Lp + 16 * it + 4 * lg);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + 4 * lg + r;
@@ -291,7 +394,7 @@ __global__ __launch_bounds__(64) void m2f_attn_bwd_kernel(const AttnBatch ab) {
                 pd[it][r] = pdv;
             }
         }
-        for (int ct = 0; ct < (W >> 4); ++ct) {
+        for (int ct = wv; ct < (W >> 4); ct += NWAVE) {
             f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < NT; ++it) {
@@ -333,7 +436,8 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
         const int W = (p.hd + 15) & ~15;
         if (W > maxW) maxW = W;
     }
-    const size_t lds = (size_t)(BWD ? 4 : 3) * Lp * (maxW + 2) * sizeof(float) + (BWD ? Lp * sizeof(float) : 0);
+    ab.bwd_fast = BWD && Lp * (maxW >> 2) <= NTHR * 4;     // every problem's slabs fit the 4-vector register form
+    const size_t lds = (size_t)(BWD ? (ab.bwd_fast ? 5 : 4) : 3) * Lp * (maxW + 2) * sizeof(float) + (BWD ? Lp * sizeof(float) : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define M2F_ATTN_CASE(N)                                                                                   \
     case N: {                                                                                              \
@@ -343,7 +447,7 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
             if (e != hipSuccess) return e;                                                                 \
         }                                                                                                  \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, ab);                                 \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(NTHR), lds, stream, ab);                                 \
         break;                                                                                             \
     }
     switch (NT) {

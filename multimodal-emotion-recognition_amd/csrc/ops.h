@@ -105,6 +105,7 @@ struct AttnBatch {
     uint32_t drop_thresh;
     float drop_scale;
     ShadowMap sh;              // out (fwd) / dq, dk, dv (bwd) also written as bf16
+    int bwd_fast;              // set by the launcher: LDS holds the fifth (O) slab of the one-round-trip backward path
 };
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
 hipError_t m2f_launch_attn_bwd(AttnBatch& ab, hipStream_t stream);

@@ -218,48 +218,114 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
                                               int lane, int wm, int wn) {
     const int M = P.M, N = P.N;
     const uint32_t flags = P.flags;
-    const float* bias = P.bias;
-    const float* res = P.res;
-    const float* gate = P.gate;
-    float* C = P.c;
-    uint16_t* C16 = m2f_shadow_of(gb.sh, C);
+    const float* __restrict__ bias = P.bias;
+    const char* __restrict__ res = reinterpret_cast<const char*>(P.res);
+    const char* __restrict__ gate = reinterpret_cast<const char*>(P.gate);
+    char* __restrict__ C = reinterpret_cast<char*>(P.c);
+    char* __restrict__ C16 = reinterpret_cast<char*>(m2f_shadow_of(gb.sh, P.c));
     const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
     const float gscale = P.gate_scale;
     const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
     const uint32_t site = P.drop_site;
     uint32_t key = 0;
     if (site) key = m2f_site_key(gb.rng, site);
+    // Everything below is indexed with 32-bit element offsets from the (uniform) base pointers - the saddr form of
+    // global_load / global_store - and every optional term sits behind ONE block-uniform branch per 32x32 block: the
+    // per-element 64-bit multiplies and branches of the first version cost 2 us (64x64 tile) to 7 us (128x128) per
+    // workgroup, more than the k-loop of these small-K problems.
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= N);         // block-uniform: no clamping / predicates needed
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
             const bool col_ok = col < N;
-            const int colc = col_ok ? col : 0;
-            const float bv = bias ? bias[colc] : 0.f;
+            const int colc = col_ok ? col : N - 1;
             const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+            const float bv = bias ? bias[colc] : 0.f;
+            // row of element r: row_base + (r & 3) + 8 * (r >> 2)
+            uint32_t oc[16], orr[16], og[16];
+            bool ok[16];
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    oc[r] = (uint32_t)((row_base + dr) * ldc + col);
+                    ok[r] = true;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + (r & 3) + 8 * (r >> 2);
+                    const int rowc = row < M ? row : M - 1;
+                    oc[r] = (uint32_t)(rowc * ldc + colc);
+                    ok[r] = row < M && col_ok;
+                }
+            }
             float rv[16], gv[16], cv[16];
+            if (res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + (r & 3) + 8 * (r >> 2);
+                    orr[r] = (uint32_t)((interior ? row : (row < M ? row : M - 1)) * ldres + colc);
+                    rv[r] = *reinterpret_cast<const float*>(res + (size_t)(orr[r] * 4u));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
+            if (gate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + (r & 3) + 8 * (r >> 2);
+                    og[r] = (uint32_t)((interior ? row : (row < M ? row : M - 1)) * ldgate + colc);
+                    gv[r] = *reinterpret_cast<const float*>(gate + (size_t)(og[r] * 4u));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gv[r] = 1.f;
+            }
+            if (accum) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cv[r] = *reinterpret_cast<const float*>(C + (size_t)(oc[r] * 4u));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cv[r] = 0.f;
+            }
+            float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row_base + (r & 3) + 8 * (r >> 2);
-                const int rowc = row < M ? row : 0;
-                rv[r] = res ? res[(size_t)rowc * ldres + colc] : 0.f;
-                gv[r] = gate ? gate[(size_t)rowc * ldgate + colc] : 1.f;
-                cv[r] = accum ? C[(size_t)rowc * ldc + colc] : 0.f;
+                float x = acc[i][j][r] + bv;
+                if (relu_out) x = fmaxf(x, 0.f);
+                v[r] = x;
+            }
+            if (site) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + (r & 3) + 8 * (r >> 2);
+                    v[r] = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? v[r] * gb.drop_scale : 0.f;
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row_base + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bv;
-                if (relu_out) v = fmaxf(v, 0.f);
-                if (site) v = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? v * gb.drop_scale : 0.f;
-                v += rv[r];
-                if (gate) v = gv[r] > 0.f ? v * gscale : 0.f;
-                v += cv[r];
-                if (row < M && col_ok) {
-                    C[(size_t)row * ldc + col] = v;
-                    if (C16) C16[(size_t)row * ldc + col] = m2f_bf16_bits(v);
+                float x = v[r] + rv[r];
+                if (gate) x = gv[r] > 0.f ? x * gscale : 0.f;
+                v[r] = x + cv[r];
+            }
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(C + (size_t)(oc[r] * 4u)) = v[r];
+                if (C16) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *reinterpret_cast<uint16_t*>(C16 + (size_t)(oc[r] * 2u)) = m2f_bf16_bits(v[r]);
                 }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) {
+                        *reinterpret_cast<float*>(C + (size_t)(oc[r] * 4u)) = v[r];
+                        if (C16) *reinterpret_cast<uint16_t*>(C16 + (size_t)(oc[r] * 2u)) = m2f_bf16_bits(v[r]);
+                    }
             }
         }
     }
@@ -517,7 +583,8 @@ struct Stage16KC {                       // element (row, k) at q[row*ld + k]
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int kc = (tid_ + 256 * t) % KCH;
-                const uint32_t o = (kbase + 8 * kc < kpad_) ? off[t] : off[t] - 16u * kc;      // else: this tile's first chunk
+                uint32_t o = (kbase + 8 * kc < kpad_) ? off[t] : off[t] - 16u * kc;      // else: this tile's first chunk
+                if (kseg == 0) o = 0u;            // dead tile past the end of the k-loop: every lane reads the same 16 bytes
                 v[t] = ld16(pt, o);
             }
         }
@@ -576,6 +643,7 @@ struct Stage16RC {   // element (row, k) at q[k*ld + row]; one 8(k) x 8(row) pat
         for (int j = 0; j < 8; ++j) {
             int o = off + j * ld_;
             if (!full_) o = (kbase + 8 * kp_ + j < kseg) ? o : off - 8 * kp_ * ld_ - kbase * ld_;   // else: k = 0 row
+            if (kseg == 0) o = 0;                 // dead tile past the end of the k-loop: one broadcast line
             v[j] = *reinterpret_cast<const uint4*>(pt + o);
         }
     }
@@ -632,7 +700,13 @@ __device__ __forceinline__ bf16x8 frag_from_kmajor(const char* img, int rowk, in
 // of it (measured before the split: 0.62 us per 128-wide k-tile, ~40 % of it instruction issue of one wave per SIMD,
 // MFMA busy 13 %).  The two roles run separate loops with the same barrier count, so their register sets (the load ring
 // vs accumulators + fragments) overlap in the allocation instead of adding up.
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+#ifdef M2F_EXP_TIMING
+__device__ unsigned long long m2f_dbg[64];
+#define M2F_TS(slot) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) m2f_dbg[(slot) + (threadIdx.x >= 256 ? 16 : 0)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define M2F_TS(slot) do {} while (0)
+#endif
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool TABLE>
 __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     static_assert(!(A_RC && !B_RC), "layouts: NT, NN, TN");
     constexpr bool TN = A_RC && B_RC;
@@ -649,22 +723,30 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
 
     const bool producer = threadIdx.x >= 256;                   // wave-uniform
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
-    const int bpos = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    char* ldsA = smem;
+    char* ldsB = smem + 2 * LDS_A;
+    float* red = reinterpret_cast<float*>(smem + 2 * LDS_A + 2 * LDS_B);      // bias-grad partials: own region, so the
+    constexpr int KP = BK / 8, RP = BM / 8;                                     // next tile's staging never overwrites them
+    // PERSISTENT tile loop: a launch has at most chip-filling size; workgroup b walks tiles b, b + grid, ...  Both
+    // roles see the same tile sequence and the same number of barriers per tile.  The producers of tile t+1 start as
+    // soon as the last k-tile of t has been multiplied, i.e. they fetch under the consumers' epilogue of tile t.
+    const int total_tiles = TABLE ? gb.total_tiles : (int)gridDim.x;
+    M2F_TS(0);
+  for (int bpos = xcd_remap((int)blockIdx.x, (int)gridDim.x); bpos < total_tiles; bpos += (int)gridDim.x) {
     int pi = 0;
+    if constexpr (TABLE) pi = gb.tile_prob[bpos];
+    else {
 #pragma unroll
-    for (int i = 1; i < M2F_GEMM_MAX_PROBLEMS; ++i)
-        if (i < gb.count && bpos >= gb.pr[i].tile_begin) pi = i;
-    const GemmProblem& P = gb.pr[pi];
+        for (int i = 1; i < M2F_GEMM_MAX_PROBLEMS; ++i)
+            if (i < gb.count && bpos >= gb.pr[i].tile_begin) pi = i;
+    }
+    const GemmProblem& P = TABLE ? gb.table[pi] : gb.pr[pi];
     const int M = P.M, N = P.N;
     const int tl = bpos - P.tile_begin;
     const int tiles_m = (M + BM - 1) / BM;
     const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;       // M fastest: neighbours share the B panel
     const int nk0 = (P.a.k[0] + BK - 1) / BK, nk = nk0 + (P.a.k[1] + BK - 1) / BK;
-    char* ldsA = smem;
-    char* ldsB = smem + 2 * LDS_A;
     const bool has_bg = TN && P.bias_grad != nullptr && n0 == 0;        // block-uniform
-    float* red = reinterpret_cast<float*>(smem);                        // bias-grad partials (after the k-loop)
-    constexpr int KP = BK / 8, RP = BM / 8;
 
     if (producer) {
         // ================================ PRODUCER: global -> registers -> LDS ================================
@@ -723,11 +805,15 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
             }
         };
 
+        M2F_TS(1);
 #pragma unroll
         for (int i = 0; i < D; ++i) issue(sets[i], i);
+        M2F_TS(2);
         store(sets[0], 0);
+        M2F_TS(3);
         lds_barrier();                                          // (B0) tile 0 visible
         issue(sets[0], D);
+        M2F_TS(4);
         for (int kt0 = 0; kt0 < nk; kt0 += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -750,7 +836,8 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
                 lds_barrier();                                   // (B2)
             }
         }
-        return;                                                 // every issued load was consumed or is dead: nothing to drain
+        M2F_TS(5);
+        continue;                                               // next tile (every issued load was consumed or is dead)
     }
 
     // ==================================== CONSUMER: LDS -> MFMA -> epilogue ====================================
@@ -795,7 +882,9 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     };
 
+    M2F_TS(1);
     lds_barrier();                                              // (B0)
+    M2F_TS(2);
     for (int kt0 = 0; kt0 < nk; kt0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -815,7 +904,10 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
             }
         }
     }
+    M2F_TS(3);
     gemm_epilogue<MI, NI, BM, BN>(gb, P, acc, m0, n0, lane, wm, wn);
+    M2F_TS(4);
+  }
 }
 
 // Two register budgets of the same body.  "wide": up to 256 VGPRs, one workgroup (8 waves) per CU - the launches with
@@ -823,17 +915,26 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
 // workgroups per CU with a shallower ring each - the launches with more tiles than CUs.
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
 __global__ __launch_bounds__(512) void m2f_gemm16_kernel(const GemmBatch gb) {
-    gemm16_body<A_RC, B_RC, BM, BN, BK, D>(gb);
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D, false>(gb);
 }
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void m2f_gemm16_dense_kernel(const GemmBatch gb) {
-    gemm16_body<A_RC, B_RC, BM, BN, BK, D>(gb);
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D, false>(gb);
+}
+// TABLE form: problems in device memory, persistent walk over the tile list
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(512) void m2f_gemm16_table_kernel(const GemmBatch gb) {
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D, true>(gb);
+}
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void m2f_gemm16_table_dense_kernel(const GemmBatch gb) {
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D, true>(gb);
 }
 
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false>
 hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
     constexpr int lds = 2 * (A_RC ? Stage16RC<BM, BK>::LDS_BYTES : Stage16KC<BM, BK>::LDS_BYTES) +
-                        2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES);
+                        2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES) + (BK / 8) * BM * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!DENSE || 2 * lds <= 160 * 1024, "two workgroups per CU");
     void (*kern)(const GemmBatch);
@@ -985,7 +1086,57 @@ bool vec_ok(const GemmOperand& o, bool rc, int rows) {
     return true;
 }
 
+template <int BM, int BN, int BK, int D, bool DENSE>
+hipError_t launch_table16(const GemmBatch& gb, hipStream_t stream) {
+    constexpr int lds = 2 * Stage16KC<BM, BK>::LDS_BYTES + 2 * Stage16KC<BN, BK>::LDS_BYTES + (BK / 8) * BM * 4;
+    static_assert(lds <= 160 * 1024 && (!DENSE || 2 * lds <= 160 * 1024), "LDS budget");
+    void (*kern)(const GemmBatch);
+    if constexpr (DENSE) kern = m2f_gemm16_table_dense_kernel<false, false, BM, BN, BK, D>;
+    else kern = m2f_gemm16_table_kernel<false, false, BM, BN, BK, D>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    const int slots = 256 * (DENSE ? 2 : 1);                    // workgroups the chip holds at once
+    const int grid = gb.total_tiles < slots ? gb.total_tiles : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, gb);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob) {
+    tile_prob.clear();
+    if (prs.size() > 65535) return -1;
+    int t = 0;
+    for (size_t i = 0; i < prs.size(); ++i) {
+        GemmProblem& p = prs[i];
+        p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0;
+        p.tile_begin = t;
+        p.tiles_n = m2f_cdiv(p.N, tile);
+        const int n = m2f_cdiv(p.M, tile) * p.tiles_n;
+        for (int j = 0; j < n; ++j) tile_prob.push_back((uint16_t)i);
+        t += n;
+    }
+    return t;
+}
+
+#ifdef M2F_EXP_TIMING
+extern "C" int m2f_dbg_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(m2f_dbg), sizeof(unsigned long long) * 64);
+}
+#endif
+
+hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
+    if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
+    if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
+    if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);
+    return hipErrorInvalidValue;
+}
 
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream) {
     if (gb.count <= 0 || gb.count > M2F_GEMM_MAX_PROBLEMS) return hipErrorInvalidValue;

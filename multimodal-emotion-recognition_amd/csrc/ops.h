@@ -73,11 +73,25 @@ struct GemmBatch {
     unsigned* splitk_cnt;
     int splitk_max_tiles;
     ShadowMap sh;             // C (when it lies in the workspace) is also written as bf16
+    // TABLE form (m2f_launch_gemm_table): the problems live in device memory and a launch of at most chip-filling size
+    // walks the whole tile list (persistent workgroups).  table[i] has tile_begin / tiles_n filled in for `table_tile`;
+    // tile_prob[t] = index of the problem tile t belongs to.  pr[] / count are unused in this form.
+    const GemmProblem* table;
+    const uint16_t* tile_prob;
+    int total_tiles;
+    int table_tile;           // 64 or 128
 };
 #define M2F_SPLITK_MAX_TILES 512
 
 // Launches one grouped GEMM. Returns hipSuccess or the launch error. `tile` = 0 (auto), 64 or 128.
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream);
+// TABLE form, bf16 mode, k-contiguous (NT) operands staged from gb.table[i].{a,b}.q.  Host-side preparation of a table:
+// m2f_gemm_table_layout fills tile_begin / tiles_n of every problem for `tile` and returns the tile -> problem map.
+hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream);
+#ifdef __cplusplus
+#include <vector>
+int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob);
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Attention (one wavefront per (dialogue, head); Q/K/V tiles staged in LDS, fp32 MFMA 16x16x4,
@@ -172,6 +186,16 @@ struct CastItem { const float* src; uint16_t* dst; int rows, cols, lds, ldd; uin
 #define M2F_CAST_MAX_ITEMS 48
 struct CastBatch { CastItem it[M2F_CAST_MAX_ITEMS]; int count; };
 hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream);
+
+// Token-transposed bf16 copies of activations for the weight-gradient GEMMs: dst[f*ldt + t] = bf16(relu?(src[t*ld + f]))
+// for f < F, t < T; columns T..ldt-1 of dst are written as zero.  With both operands of dW = dY^T X stored
+// [feature][token] the weight gradient runs as the k-contiguous (forward-form) GEMM.  colsum (nullable): [F] sums over
+// tokens of the fp32 source = the bias gradient when src is dY (fixed summation order: deterministic).
+// The item table lives in device memory; block_item[b] = item of workgroup b, items[i].block_begin = its first workgroup
+// (one workgroup per 64 features).
+struct TransItem { const float* src; int ld, F; uint16_t* dst; int ldt; float* colsum; int relu; int block_begin; };
+struct TransBatch { const TransItem* items; const uint16_t* block_item; int blocks; int T; };
+hipError_t m2f_launch_transpose_tokens(const TransBatch& tb, hipStream_t stream);
 
 // Dialogue batcher (replaces Dataset.__getitem__ + collate_fn, reference src/dataset.py:32-89, on the device): token slot t
 // takes row rows[t] of the two device-resident embedding tables (rows[t] < 0: padded slot -> zeros, label -1, key_pad 1).

@@ -230,13 +230,16 @@ struct m2f_plan {
     uint16_t* wshadow = nullptr;
     std::vector<CastBatch> casts;        // parameters + input staging -> bf16, at the start of every forward
     std::vector<Launch> fwd, bwd;
-    // deferred weight-gradient launches run on a second stream, each as soon as the chain launch that produces its last
-    // operand has been issued (wg_dep = index into bwd, -1 = operands come from the forward pass / criterion)
+    // deferred weight-gradient launches, run after the backward chain on the same stream.  (Overlapping them with the
+    // chain on a second stream was measured SLOWER inside the captured graph: every fork costs the chain a 12-16 us
+    // cross-queue gap and the chain's small GEMMs run ~2x longer next to a chip-filling launch; 2.85 -> 2.77 ms/step.)
     std::vector<Launch> wg;
-    std::vector<int> wg_dep;
-    hipStream_t aux = nullptr;
-    std::vector<hipEvent_t> wg_ev;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // bf16 mode: all weight gradients as ONE persistent k-contiguous GEMM launch over a device-resident problem table,
+    // fed by token-transposed bf16 copies of dY / X made by one transposing launch (which also sums the bias gradients)
+    bool wg_nt = false;
+    TransBatch wg_trans = {nullptr, nullptr, 0, 0};
+    GemmBatch wg_tab;
+    double wg_flops = 0.0;
     std::vector<LnReduceBatch> lnred;
     size_t ws_used = 0;
     // graph cache for m2f_step
@@ -245,10 +248,6 @@ struct m2f_plan {
     bool warmed = false;          // one eager step (sets kernel attributes) before the first capture
     ~m2f_plan() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
-        for (hipEvent_t e : wg_ev) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (aux) (void)hipStreamDestroy(aux);
     }
 };
 
@@ -824,15 +823,12 @@ int build_plan(m2f_plan& P, char* ws_base) {
         size_t i = 0;
         while (i < order.size()) {
             Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
-            int dep = -1;
             const bool kind0 = shadowable(bld.wgrads[order[i].second]);
             while (i < order.size() && o.gp.size() < M2F_GEMM_MAX_PROBLEMS && shadowable(bld.wgrads[order[i].second]) == kind0) {
                 o.gp.push_back(bld.wgrads[order[i].second]);
-                dep = std::max(dep, order[i].first);
                 ++i;
             }
             wops.push_back(o);
-            P.wg_dep.push_back(dep);
         }
         to_launches(P, wops, P.wg);
         for (size_t i = 0; i < bld.lnitems.size(); i += M2F_LNRED_MAX_ITEMS) {
@@ -847,11 +843,70 @@ int build_plan(m2f_plan& P, char* ws_base) {
     const size_t ws_floats = bld.ar.off / 4;
     uint16_t* shadow = bld.ar.alloc<uint16_t>(ws_floats);
     uint16_t* wshadow = bld.ar.alloc<uint16_t>(P.pm.shadow_elems + 64);
+    // ---- weight-gradient table (bf16 mode): token-transposed operand copies, problem table, tile map ------------------
+    std::vector<TransItem> titems;
+    std::vector<uint16_t> tblock;
+    std::vector<GemmProblem> tprobs;
+    std::vector<uint16_t> tile_prob;
+    bool table_ok = P.train && !bld.wgrads.empty();
+    const int ldt = (T + 7) & ~7;
+    if (table_ok) {
+        auto item_of = [&](const float* src, int ld, int F, int relu) {
+            for (size_t k = 0; k < titems.size(); ++k)
+                if (titems[k].src == src && titems[k].ld == ld && titems[k].F == F && titems[k].relu == relu) return (int)k;
+            TransItem it;
+            it.src = src; it.ld = ld; it.F = F; it.relu = relu; it.colsum = nullptr; it.ldt = ldt;
+            it.dst = bld.ar.alloc<uint16_t>((size_t)F * ldt);
+            it.block_begin = (int)tblock.size();
+            for (int b = 0; b < (F + 63) / 64; ++b) tblock.push_back((uint16_t)titems.size());
+            titems.push_back(it);
+            return (int)titems.size() - 1;
+        };
+        for (const GemmProblem& g : bld.wgrads) {
+            if (g.a.k[1] != 0 || g.b.k[1] != 0 || titems.size() > 60000) { table_ok = false; break; }
+            const int ia = item_of(g.a.p[0], g.a.ld[0], g.M, (g.flags & GF_RELU_A) ? 1 : 0);
+            const int ib = item_of(g.b.p[0], g.b.ld[0], g.N, (g.flags & GF_RELU_B) ? 1 : 0);
+            if (g.bias_grad) {
+                if (titems[ia].colsum && titems[ia].colsum != g.bias_grad) { table_ok = false; break; }
+                titems[ia].colsum = g.bias_grad;
+            }
+            GemmProblem q;
+            memset(&q, 0, sizeof(q));
+            q.a.q[0] = titems[ia].dst; q.a.ldq[0] = ldt; q.a.k[0] = T;
+            q.b.q[0] = titems[ib].dst; q.b.ldq[0] = ldt; q.b.k[0] = T;
+            q.M = g.M; q.N = g.N; q.c = g.c; q.ldc = g.ldc; q.gate_scale = 1.f;
+            q.flags = g.flags & ~(uint32_t)(GF_RELU_A | GF_RELU_B);
+            tprobs.push_back(q);
+            P.wg_flops += 2.0 * g.M * g.N * (double)T;
+        }
+        if (tblock.size() > 65535) table_ok = false;
+    }
+    int total_tiles = 0;
+    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, 128, tile_prob);
+    if (total_tiles <= 0) table_ok = false;
+    GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;
+    uint16_t* d_tile_prob = table_ok ? bld.ar.alloc<uint16_t>(tile_prob.size()) : nullptr;
+    TransItem* d_items = table_ok ? bld.ar.alloc<TransItem>(titems.size()) : nullptr;
+    uint16_t* d_tblock = table_ok ? bld.ar.alloc<uint16_t>(tblock.size()) : nullptr;
     P.ws_used = bld.ar.off;
+    if (table_ok && P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
+        bool ok = hipMemcpy(d_table, tprobs.data(), tprobs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_tile_prob, tile_prob.data(), tile_prob.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_items, titems.data(), titems.size() * sizeof(TransItem), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_tblock, tblock.data(), tblock.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            P.wg_nt = true;
+            P.wg_trans = {d_items, d_tblock, (int)tblock.size(), T};
+            memset(&P.wg_tab, 0, sizeof(P.wg_tab));
+            P.wg_tab.table = d_table; P.wg_tab.tile_prob = d_tile_prob; P.wg_tab.total_tiles = total_tiles; P.wg_tab.table_tile = 128;
+            P.wg_tab.rng = P.rng; P.wg_tab.drop_thresh = P.drop_thresh; P.wg_tab.drop_scale = P.drop_scale;
+        }
+    }
     if (P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
         const float* wsf = reinterpret_cast<const float*>(ws_base);
         P.sh = {wsf, shadow, ws_floats};
         P.wshadow = wshadow;
+        P.wg_tab.sh = P.sh;
         auto map_q = [&](GemmOperand& o) {
             for (int sgm = 0; sgm < 2; ++sgm) {
                 o.q[sgm] = nullptr; o.ldq[sgm] = 0; o.qt[sgm] = nullptr; o.ldqt[sgm] = 0;
@@ -975,30 +1030,15 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
 
 int do_backward(m2f_plan& P, hipStream_t s) {
     if (!P.train || !P.grads) return fail("m2f_backward: plan was created without train=1 / gradient buffer");
-    const bool overlap = P.aux != nullptr && g_prof == nullptr && !P.wg.empty();
-    if (!overlap) {                                  // serial: chain, then the weight gradients (per-launch timing mode)
-        if (int r = run_launches(P, P.bwd, s)) return r;
-        if (int r = run_launches(P, P.wg, s)) return r;
+    if (int r = run_launches(P, P.bwd, s)) return r;
+    if (P.wg_nt) {
+        if (g_prof) g_prof->begin(10, 0.0);
+        M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
+        if (g_prof) { g_prof->end(); g_prof->begin(M2F_LAYOUT_TN, P.wg_flops); }
+        M2F_HIP(m2f_launch_gemm_table(P.wg_tab, s));
+        if (g_prof) g_prof->end();
     } else {
-        // fork: the aux stream sees everything issued so far (forward activations, dlogits)
-        M2F_HIP(hipEventRecord(P.ev_fork, s));
-        M2F_HIP(hipStreamWaitEvent(P.aux, P.ev_fork, 0));
-        size_t g = 0;
-        for (; g < P.wg.size() && P.wg_dep[g] < 0; ++g)
-            if (int r = run_launches(P, P.wg, P.aux, g, 1)) return r;
-        for (size_t i = 0; i < P.bwd.size(); ++i) {
-            if (int r = run_launches(P, P.bwd, s, i, 1)) return r;
-            if (g < P.wg.size() && P.wg_dep[g] <= (int)i) {
-                M2F_HIP(hipEventRecord(P.wg_ev[g], s));
-                M2F_HIP(hipStreamWaitEvent(P.aux, P.wg_ev[g], 0));
-                for (; g < P.wg.size() && P.wg_dep[g] <= (int)i; ++g)
-                    if (int r = run_launches(P, P.wg, P.aux, g, 1)) return r;
-            }
-        }
-        for (; g < P.wg.size(); ++g)
-            if (int r = run_launches(P, P.wg, P.aux, g, 1)) return r;
-        M2F_HIP(hipEventRecord(P.ev_join, P.aux));
-        M2F_HIP(hipStreamWaitEvent(s, P.ev_join, 0));
+        if (int r = run_launches(P, P.wg, s)) return r;
     }
     for (const LnReduceBatch& rb : P.lnred) {
         if (g_prof) g_prof->begin(9, 0.0);
@@ -1080,15 +1120,6 @@ m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, in
     }
     p->params = params; p->grads = grads; p->rng = rng_state;
     build_plan(*p, static_cast<char*>(workspace));
-    if (train && !p->wg.empty()) {
-        bool ok = hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
-        p->wg_ev.resize(p->wg.size(), nullptr);
-        for (size_t i = 0; ok && i < p->wg.size(); ++i)
-            ok = hipEventCreateWithFlags(&p->wg_ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { fail("could not create the auxiliary stream / events"); delete p; return nullptr; }
-    }
     if ((int64_t)p->ws_used > workspace_bytes) {
         fail("workspace too small: need " + std::to_string(p->ws_used) + " bytes");
         delete p;
@@ -1107,7 +1138,7 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (phase == 0) return (int)(plan->fwd.size() + plan->casts.size());
     if (phase == 1) return 2;
-    return (int)(plan->bwd.size() + plan->wg.size() + plan->lnred.size());
+    return (int)(plan->bwd.size() + (plan->wg_nt ? 2 : plan->wg.size()) + plan->lnred.size());
 }
 
 static int do_forward(m2f_plan& P, hipStream_t s) {

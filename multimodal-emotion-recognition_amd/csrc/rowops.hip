@@ -491,6 +491,56 @@ __global__ __launch_bounds__(256) void m2f_cast_t_kernel(const CastBatch cb) {
     }
 }
 
+// [T, F] fp32 -> [F, ldt] bf16 (tokens contiguous), 64 features per workgroup, 64-token tiles through LDS: reads are
+// 256-byte rows of the source, writes 128-byte rows of the destination.
+__global__ __launch_bounds__(256) void m2f_transpose_tokens_kernel(const TransBatch tb) {
+    __shared__ float tile[64][65];
+    __shared__ float part[4][64];
+    const TransItem& it = tb.items[tb.block_item[blockIdx.x]];
+    const int f0 = ((int)blockIdx.x - it.block_begin) * 64;
+    const int T = tb.T;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;           // 64 x 4
+    const bool fok = f0 + lx < it.F;
+    const float* src = it.src + f0 + (fok ? lx : 0);
+    const bool relu = it.relu != 0;
+    float cs = 0.f;
+    for (int t0 = 0; t0 < it.ldt; t0 += 64) {
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                                  // unconditional clamped loads, then select
+            const int t = t0 + ly + 4 * i;
+            x[i] = src[(size_t)(t < T ? t : T - 1) * it.ld];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = t0 + ly + 4 * i;
+            float v = (fok && t < T) ? x[i] : 0.f;
+            cs += v;
+            if (relu) v = fmaxf(v, 0.f);
+            tile[ly + 4 * i][lx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = ly + 4 * i, t = t0 + lx;                      // lanes: consecutive tokens of one feature
+            if (f0 + f < it.F && t < it.ldt) it.dst[(size_t)(f0 + f) * it.ldt + t] = m2f_bf16_bits(tile[lx][f]);
+        }
+        __syncthreads();
+    }
+    if (it.colsum) {                                                    // block-uniform
+        part[ly][lx] = cs;
+        __syncthreads();
+        if (ly == 0 && fok) it.colsum[f0 + lx] = (part[0][lx] + part[1][lx]) + (part[2][lx] + part[3][lx]);
+    }
+}
+
+hipError_t m2f_launch_transpose_tokens(const TransBatch& tb, hipStream_t stream) {
+    if (tb.blocks <= 0) return hipSuccess;
+    if (!tb.items || !tb.block_item || tb.T < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(m2f_transpose_tokens_kernel, dim3(tb.blocks), dim3(256), 0, stream, tb);
+    return hipGetLastError();
+}
+
 hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream) {
     if (cb.count <= 0) return hipSuccess;
     if (cb.count > M2F_CAST_MAX_ITEMS) return hipErrorInvalidValue;

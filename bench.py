@@ -161,6 +161,18 @@ def main():
         elapsed = dp.reduce_metrics([elapsed], device=device)[0]
         loss = float(stepper.reducer.global_loss().item())
 
+        # ---- secondary figure: forward + criterion + backward only (SURVEY 8-d's strict metric; `value` above also
+        # pays for the optimizer and, at N > 1, the gradient exchange) ---------------------------------------------
+        n_fb = max(10, min(args.steps, 50))
+        for _ in range(3):
+            plan.step(0.1, False, False, use_graph)
+        side.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(n_fb):
+            plan.step(0.1, False, False, use_graph)
+        side.synchronize()
+        fb_sec = (time.perf_counter() - tf0) / n_fb
+
         # ---- roofline of the dominant kernel (grouped GEMM), per-launch hipEvent timing ------------------
         rows = []
         for _ in range(5):
@@ -185,6 +197,17 @@ def main():
     utt_per_s = world * B * L / (elapsed / args.steps)
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
+    # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process, so the figure comes from the
+    # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/traffic.sh), if present
+    traffic, traffic_src = None, None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"traffic_{args.workload}_{args.dtype}.json")
+    if os.path.exists(tf):
+        try:
+            with open(tf) as f:
+                traffic = float(json.load(f)["traffic_bytes_per_launch"])
+            traffic_src = os.path.relpath(tf, os.path.dirname(os.path.abspath(__file__)))
+        except (OSError, ValueError, KeyError):
+            traffic = None
 
     if rank == 0:
         out = {
@@ -198,11 +221,14 @@ def main():
                        "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                        "launches_per_step": plan.num_launches()},
             "loss": loss,
+            "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": B * L / fb_sec, "steps": n_fb,
+                             "note": "fwd + CE + bwd graph replays on rank 0, optimizer and gradient exchange excluded"},
             "step_tflops": utt_per_s * fb_per_slot / 1e12,
             "step_frac_of_peak": utt_per_s * fb_per_slot / 1e12 / (peak * world),
             "roofline": {
                 "bound": "mfma", "kernel": "m2f_gemm_kernel (grouped MFMA GEMM: forward / dgrad / wgrad forms)",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches_per_step": len(gemm_idx), "avg_launch_us": gemm_ms / max(len(gemm_idx), 1) * 1e3,
                 "algorithmic_gflop_per_step": gemm_fl / 1e9, "gemm_ms_per_step": gemm_ms,
                 "all_kernels_ms_per_step_eager": sum(avg_ms),

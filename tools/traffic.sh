@@ -44,6 +44,7 @@ out = {"workload": bench["config"]["workload"], "dtype": bench["dtype"], "gemm_d
        "gemm_hbm_bytes_per_launch": {"read": g_rd * (cal_rd or 0), "write": g_wr * (cal_wr or 0)},
        "by_kernel_raw": {C: {k: {"sum": v, "n": n} for k, (v, n) in sorted(per[C].items())} for C in per}}
 out["traffic_bytes_per_launch"] = out["gemm_hbm_bytes_per_launch"]["read"] + out["gemm_hbm_bytes_per_launch"]["write"]
+out["by_kernel_raw"] = {C: {k: v for k, v in d.items() if "m2f_" in k} for C, d in out["by_kernel_raw"].items()}
 json.dump(out, open(f"{R}/gpurun_out/traffic_{tag}/traffic.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("raw_counter_per_launch", "calibration_bytes_per_count", "gemm_hbm_bytes_per_launch", "traffic_bytes_per_launch")}, indent=1))
 PY

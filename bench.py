@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--buckets", type=int, default=8)
+    ap.add_argument("--grad-exchange", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="dtype of the gradient all-reduce at N > 1 (auto: bf16 for --dtype bf16, fp32 for --dtype fp32)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch timing table (kind, us, GFLOP) to this file")
     args = ap.parse_args()
 
@@ -128,7 +130,8 @@ def main():
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=args.dtype).to(device).train()
     opt = FusedAdam(model, lr=5e-5, weight_decay=0.01)
-    stepper = dp.DataParallelStep(model, opt, n_buckets=args.buckets)
+    exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
+    stepper = dp.DataParallelStep(model, opt, n_buckets=args.buckets, exchange=exchange)
     text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device)
     eng = model.engine()
     plan = eng.plan(B, L, True, True)
@@ -217,7 +220,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B,
                        "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
-                       "step": "fwd+CE+bwd (1 hipGraph)" + (" + RCCL grad all-reduce" if world > 1 else "") + " + fused Adam",
+                       "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({exchange})" if world > 1 else "") + " + fused Adam",
                        "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                        "launches_per_step": plan.num_launches()},
             "loss": loss,

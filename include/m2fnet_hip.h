@@ -115,6 +115,13 @@ int m2f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* grad_scale_ptr, m2f_stream_t stream);
 
+/* Same update with the gradients given as bf16 (n values, 8-byte aligned): the data-parallel path can exchange
+ * gradients in bf16 over xGMI (half the bytes of the fp32 all-reduce) and feed the reduced buffer straight to the
+ * optimizer; parameters and both moments stay fp32.  No counterpart in the reference (single process). */
+int m2f_adam_step_g16(float* params, const uint16_t* grads_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      const float* grad_scale_ptr, m2f_stream_t stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the plan launches) ---------- */
 /* C[M,N] = epilogue(A x B); layout 0: C = A[M,K] B[N,K]^T (nn.Linear forward), 1: C = A[M,K] B[K,N]
  * (input gradient), 2: C = A[K,M]^T B[K,N] (weight gradient; bias_grad[M] = column sums of A).

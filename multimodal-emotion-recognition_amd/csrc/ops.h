@@ -216,7 +216,8 @@ hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream);
 // Fused Adam with coupled L2 (torch.optim.Adam semantics, src/train.py:56) over the flat buffers.
 // grad_scale_ptr (device, may be null): gradients are multiplied by 1 / *grad_scale_ptr first (the
 // global valid-utterance denominator under data parallelism).
-hipError_t m2f_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+// g_is_bf16: g points at bf16 gradients (data-parallel bf16 exchange) instead of fp32.
+hipError_t m2f_launch_adam(float* p, const void* g, int g_is_bf16, float* m, float* v, int64_t n, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
                            hipStream_t stream);
 

@@ -1230,7 +1230,15 @@ int m2f_rng_advance(uint32_t* rng_state, m2f_stream_t stream) {
 
 int m2f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr, m2f_stream_t stream) {
-    M2F_HIP(m2f_launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale_ptr,
+    M2F_HIP(m2f_launch_adam(params, grads, 0, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale_ptr,
+                            static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_adam_step_g16(float* params, const uint16_t* grads_bf16, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
+                      m2f_stream_t stream) {
+    M2F_HIP(m2f_launch_adam(params, grads_bf16, 1, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale_ptr,
                             static_cast<hipStream_t>(stream)));
     return 0;
 }

@@ -376,13 +376,22 @@ __global__ void m2f_rng_advance_kernel(uint32_t* rng) {
     }
 }
 
-__global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// G16: the gradient buffer holds bf16 (the data-parallel bf16 exchange), everything else stays fp32
+template <bool G16>
+__global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, int64_t n4, float lr_bc1, float beta1, float beta2,
                                                        float eps, float wd, float inv_sqrt_bc2, const float* __restrict__ gs_ptr) {
     const float gs = gs_ptr ? 1.0f / *gs_ptr : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 gg;
+        if constexpr (G16) {
+            const uint2 raw = reinterpret_cast<const uint2*>(g)[i];
+            gg[0] = __builtin_bit_cast(float, raw.x << 16); gg[1] = __builtin_bit_cast(float, raw.x & 0xFFFF0000u);
+            gg[2] = __builtin_bit_cast(float, raw.y << 16); gg[3] = __builtin_bit_cast(float, raw.y & 0xFFFF0000u);
+        } else {
+            gg = reinterpret_cast<const f32x4*>(g)[i];
+        }
         f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
         f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
@@ -572,7 +581,7 @@ hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t m2f_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+hipError_t m2f_launch_adam(float* p, const void* g, int g_is_bf16, float* m, float* v, int64_t n, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
                            hipStream_t stream) {
     if (n & 3) return hipErrorInvalidValue;      // flat buffers are padded to 64 floats per tensor
@@ -580,7 +589,11 @@ hipError_t m2f_launch_adam(float* p, const float* g, float* m, float* v, int64_t
     const int64_t n4 = n >> 2;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(m2f_adam_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, (float)(lr / bc1), beta1, beta2, eps,
-                       weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
+    if (g_is_bf16)
+        hipLaunchKernelGGL(m2f_adam_kernel<true>, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, (float)(lr / bc1), beta1, beta2,
+                           eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
+    else
+        hipLaunchKernelGGL(m2f_adam_kernel<false>, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, (float)(lr / bc1), beta1, beta2,
+                           eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
     return hipGetLastError();
 }

@@ -68,12 +68,22 @@ class GradReducer:
     collective's own stream (``async_op=True``), so a caller that produces gradients back-to-front can start
     reducing finished chunks while the rest is still being computed."""
 
-    def __init__(self, buf: torch.Tensor, n_params: int, group=None, n_buckets: int = 1):
+    def __init__(self, buf: torch.Tensor, n_params: int, group=None, n_buckets: int = 1, exchange: str = "fp32"):
+        """exchange = "fp32": the buffer itself is all-reduced (exact sum of the ranks' fp32 gradients).
+        exchange = "bf16": the parameter gradients travel as bf16 (half the xGMI bytes; the 64-float tail with the
+        loss terms stays fp32 in its own small collective) and the optimizer reads the reduced bf16 buffer directly -
+        the usual mixed-precision trade (each rank's gradient rounded once to bf16, ring partial sums in bf16), offered
+        for the bf16 compute mode only."""
         assert buf.numel() >= n_params + 3 and buf.dim() == 1
-        self.buf, self.n, self.group = buf, n_params, group
+        assert exchange in ("fp32", "bf16")
+        self.buf, self.n, self.group, self.exchange = buf, n_params, group, exchange
         n_buckets = max(1, int(n_buckets))
         edges = [round(i * buf.numel() / n_buckets / 64) * 64 for i in range(n_buckets)] + [buf.numel()]
         self.chunks = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+        # bf16 exchange: buckets over the parameter part only
+        pedges = [round(i * n_params / n_buckets / 64) * 64 for i in range(n_buckets)] + [n_params]
+        self.param_chunks = [(a, b) for a, b in zip(pedges[:-1], pedges[1:]) if b > a]
+        self.buf16 = torch.empty(n_params, dtype=torch.bfloat16, device=buf.device) if exchange == "bf16" else None
         self._work = []
 
     @property
@@ -108,6 +118,21 @@ class GradReducer:
         if not dist.is_initialized():
             optimizer.step()
             return
+        if self.exchange == "bf16":
+            tail = self.buf[self.n:]
+            work_tail = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # (loss, den, num): fp32
+            order = list(reversed(self.param_chunks))
+            work = []
+            for a, b in order:
+                self.buf16[a:b].copy_(self.buf[a:b])                     # one rounding per rank, on the device
+                work.append(dist.all_reduce(self.buf16[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+            def wait(i):
+                if i == 0:
+                    work_tail.wait()
+                work[i].wait()
+            optimizer.step_ranges(order, before_each=wait, grads=self.buf16)
+            return
         order = list(reversed(self.chunks))
         work = [dist.all_reduce(self.buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a, b in order]
         optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
@@ -134,11 +159,11 @@ class DataParallelStep:
     """One optimizer step of dialogue-sharded data-parallel training:
     m2f_step(normalise=0) -> tail <- (den, num) -> all-reduce -> fused Adam with grad_scale = global den."""
 
-    def __init__(self, model, optimizer, group=None, n_buckets: int = 4):
+    def __init__(self, model, optimizer, group=None, n_buckets: int = 4, exchange: str = "fp32"):
         self.model, self.optimizer = model, optimizer
         eng = model.engine()
         eng.ensure_grad()
-        self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets)
+        self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets, exchange)
         optimizer.grad_scale = self.reducer.global_den
 
     def __call__(self, text, audio, mask, emotion, label_smoothing: float = 0.1, class_weights=None,

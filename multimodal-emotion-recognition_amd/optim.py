@@ -106,14 +106,15 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
-    def step_ranges(self, ranges, before_each=None):
+    def step_ranges(self, ranges, before_each=None, grads=None):
         """One optimizer step issued as several kernel launches over contiguous element ranges [(lo, hi), ...] of the
         flat buffers (hi clipped to the parameter count; lo, hi multiples of 4).  `before_each(i)` runs before range i
         is launched - the data-parallel path waits there for that range's all-reduce, so the update of one bucket
-        overlaps the exchange of the next."""
+        overlaps the exchange of the next.  `grads`: gradient buffer to read instead of the engine's (same indexing;
+        fp32 or bf16 - the reduced buffer of the bf16 exchange)."""
         eng = self._bind()
         g = self.param_groups[0]
-        flat_grad = eng.ensure_grad()
+        flat_grad = eng.ensure_grad() if grads is None else grads
         n = eng.flat.numel()
         self._step += 1
         for i, (lo, hi) in enumerate(ranges):

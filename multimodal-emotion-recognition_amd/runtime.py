@@ -72,6 +72,8 @@ SIGNATURES = {
     "m2f_rng_advance": (c_int, [c_void_p, c_void_p]),
     "m2f_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_void_p, c_void_p]),
+    "m2f_adam_step_g16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                              c_float, c_int, c_void_p, c_void_p]),
     "m2f_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                          c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float,
                          c_void_p, c_int, c_int, c_int, c_int, c_uint32, c_float, c_void_p, c_int, c_void_p, c_void_p,
@@ -265,6 +267,12 @@ class Plan:
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
               lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
               grad_scale: Optional[torch.Tensor] = None) -> None:
+    """grads: fp32, or bf16 (the reduced buffer of the data-parallel bf16 exchange) - same update, fp32 state either way."""
+    if grads.dtype == torch.bfloat16:
+        check(lib().m2f_adam_step_g16(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                      params.numel(), lr, betas[0], betas[1], eps, weight_decay, step, ptr(grad_scale),
+                                      stream_ptr()), "m2f_adam_step_g16")
+        return
     check(lib().m2f_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                               params.numel(), lr, betas[0], betas[1], eps, weight_decay, step, ptr(grad_scale),
                               stream_ptr()), "m2f_adam_step")

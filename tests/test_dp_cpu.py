@@ -57,12 +57,28 @@ def _worker(rank, world, port, q):
     seen = []
 
     class FakeOpt:
-        def step_ranges(self, ranges, before_each=None):
+        def step_ranges(self, ranges, before_each=None, grads=None):
             for i, (lo, hi) in enumerate(ranges):
                 before_each(i)
                 seen.append((lo, hi, float(buf2[lo]), float(buf2[min(hi, buf2.numel()) - 1])))
     red2.reduce_and_step(FakeOpt())
     total = float(sum(range(1, world + 1)))
+    # bf16 exchange: parameter gradients travel as bf16 (own buffer handed to the optimizer), the tail stays fp32
+    buf3 = torch.cat([torch.full((1000,), 0.1 * (rank + 1)), torch.full((dp.TAIL,), float(rank + 1))])
+    red3 = dp.GradReducer(buf3, 1000, n_buckets=3, exchange="bf16")
+    seen3 = []
+
+    class FakeOpt16:
+        def step_ranges(self, ranges, before_each=None, grads=None):
+            for i, (lo, hi) in enumerate(ranges):
+                before_each(i)
+                seen3.append((lo, hi, grads.dtype, float(grads[lo]), float(grads[hi - 1]), float(buf3[1000 + 1])))
+    red3.reduce_and_step(FakeOpt16())
+    want16 = float(sum(torch.tensor(0.1 * (r + 1)).to(torch.bfloat16).float() for r in range(world)))
+    out["bf16_ok"] = (len(seen3) == 3 and all(d == torch.bfloat16 and abs(a - want16) < 2e-2 and abs(b - want16) < 2e-2 and t == total
+                                             for _, _, d, a, b, t in seen3)
+                      and sorted((lo, hi) for lo, hi, *_ in seen3) == sorted(red3.param_chunks)
+                      and float(buf3[0]) == float(torch.tensor(0.1 * (rank + 1))))       # fp32 gradients left untouched
     out["pipelined_ok"] = (all(a == total and b == total for _, _, a, b in seen) and seen[0][1] == buf2.numel()
                            and sorted((lo, hi) for lo, hi, _, _ in seen) == sorted(red2.chunks))
     means = [torch.zeros(1) for _ in range(world)]
@@ -93,6 +109,7 @@ def test_two_rank_gloo_global_denominator():
     assert abs(r0["mean_of_means"] - r0["ref_loss"]) > 1e-4, "ranks hold different valid counts: mean of means differs"
     assert r0["max_time"] == 2.0 and res[1]["max_time"] == 2.0
     assert r0["pipelined_ok"] and res[1]["pipelined_ok"]
+    assert r0["bf16_ok"] and res[1]["bf16_ok"]
 
 
 def test_shard_dialogues_partition():

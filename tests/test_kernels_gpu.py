@@ -273,3 +273,11 @@ def test_adam_matches_torch():
     p3, m3, v3 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     runtime.adam_step(p3, g, m3, v3, 1, 1e-3, (0.9, 0.999), 1e-8, 0.01)
     _close(p2, p3, 1e-6, "grad_scale")
+    # bf16 gradient input (data-parallel bf16 exchange): identical to the fp32 kernel fed the same rounded gradients
+    g16 = g.to(torch.bfloat16)
+    p4, m4, v4 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p5, m5, v5 = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        runtime.adam_step(p4, g16, m4, v4, step, 1e-3, (0.9, 0.999), 1e-8, 0.01, grad_scale=den)
+        runtime.adam_step(p5, g16.float(), m5, v5, step, 1e-3, (0.9, 0.999), 1e-8, 0.01, grad_scale=den)
+    assert torch.equal(p4, p5) and torch.equal(m4, m5) and torch.equal(v4, v5)

@@ -619,12 +619,12 @@ struct Stage16RC {   // element (row, k) at q[k*ld + row]; one 8(k) x 8(row) pat
     // disjoint bank ranges).  No register transposes, no scattered stores.
     static constexpr int KP = BK / 8, RP = BR / 8, NPATCH = KP * RP;
     static constexpr int ROWK = 2 * BR + 16, LDS_BYTES = BK * ROWK;   // +16: 2-way conflicts on the tr reads, but 2 workgroups fit a CU
-    static_assert(NPATCH == 128, "one patch per thread of a 128-thread half");
     uint4 v[8];
     int off, kp_, rp_;
     int ld_, rows_, row0_, kseg_, kbase_;
     bool full_, active_;
     __device__ __forceinline__ void setup(int ld, int rows, int row0, int pid) {
+        static_assert(NPATCH == 128, "one patch per thread of a 128-thread half");
         ld_ = ld; rows_ = rows; row0_ = row0;
         active_ = pid >= 0 && pid < NPATCH;
         const int p = active_ ? pid : 0;
@@ -1110,6 +1110,8 @@ hipError_t launch_table16(const GemmBatch& gb, hipStream_t stream) {
 }  // namespace
 
 int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob) {
+    // tile = 64: 64x64, 128: 128x128, 256: 256 (M) x 128 (N)
+    const int tile_m = tile, tile_n = tile == 256 ? 128 : tile;
     tile_prob.clear();
     if (prs.size() > 65535) return -1;
     int t = 0;
@@ -1117,8 +1119,8 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
         GemmProblem& p = prs[i];
         p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0;
         p.tile_begin = t;
-        p.tiles_n = m2f_cdiv(p.N, tile);
-        const int n = m2f_cdiv(p.M, tile) * p.tiles_n;
+        p.tiles_n = m2f_cdiv(p.N, tile_n);
+        const int n = m2f_cdiv(p.M, tile_m) * p.tiles_n;
         for (int j = 0; j < n; ++j) tile_prob.push_back((uint16_t)i);
         t += n;
     }
@@ -1133,6 +1135,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
+    if (gb.table_tile == 256) return launch_table16<256, 128, 64, 2, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);
     return hipErrorInvalidValue;

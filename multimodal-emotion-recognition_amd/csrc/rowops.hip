@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
         RowRegs<NV> x, dy;
         row_load(x, P.x + (size_t)row * ld, d, vec, lane);
         row_load(dy, P.dy + (size_t)row * ld, d, vec, lane);
+        RowRegs<NV> ex;                                         // fetched with x / dy: one memory round trip, not two
+        if (P.extra) row_load(ex, P.extra + (size_t)row * ld, d, vec, lane);
         const float mean = P.stats[2 * row], rstd = P.stats[2 * row + 1];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -174,8 +176,6 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
                 db.v[j][e] += dy.v[j][e];
             }
         const float c1 = m2f_wave_sum(s1) * invd, c2 = m2f_wave_sum(s2) * invd;
-        RowRegs<NV> ex;
-        if (P.extra) row_load(ex, P.extra + (size_t)row * ld, d, vec, lane);
         RowRegs<NV> msk;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -221,7 +221,19 @@ __global__ __launch_bounds__(256) void m2f_ln_param_reduce_kernel(const LnReduce
     if (c < it.d) {
         const int per = (it.nblk + 3) / 4;
         const int b0 = w * per, b1 = b0 + per < it.nblk ? b0 + per : it.nblk;
-        for (int b = b0; b < b1; ++b) {
+        // batches of 8 row blocks: 16 independent loads in flight per lane, summed in the fixed order b0, b0+1, ...
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float g[8], be[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                g[u] = it.partial[(size_t)(b + u) * 2 * it.d + c];
+                be[u] = it.partial[(size_t)(b + u) * 2 * it.d + it.d + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sg += g[u]; sb += be[u]; }
+        }
+        for (; b < b1; ++b) {
             sg += it.partial[(size_t)b * 2 * it.d + c];
             sb += it.partial[(size_t)b * 2 * it.d + it.d + c];
         }

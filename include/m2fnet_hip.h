@@ -122,6 +122,28 @@ int m2f_adam_step_g16(float* params, const uint16_t* grads_bf16, float* exp_avg,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       const float* grad_scale_ptr, m2f_stream_t stream);
 
+/* ---- in-loop text encoder (BASELINE config C5) -------------------------------------------------
+ * The reference computes its text embeddings with transformers' RobertaModel (src/feature_extractors/text/model.py:16-21,
+ * [CLS] pooling at text/embeddings.py:83) in a separate stage; these entry points are the pieces that model needs beyond
+ * the GEMM / LayerNorm kernels below, so the encoder can run in the training loop on the same device buffers. */
+
+/* Outputs of m2f_gemm / m2f_layernorm_fwd / m2f_embed_layernorm / m2f_attention_long_fwd that lie inside
+ * [ws_base, ws_base + floats) are ALSO written as bf16 at the same element index of `shadow` (the operand copies the
+ * bf16 GEMM stages from).  NULL, NULL, 0 switches it off.  Thread-local. */
+int m2f_set_shadow_map(const float* ws_base, uint16_t* shadow, int64_t floats);
+
+/* RobertaEmbeddings.forward in eval mode: out[t] = LayerNorm(word_emb[input_ids[t]] + pos_emb[position_ids[t]] +
+ * token_type_emb[0]) for T tokens of width d (d % 4 == 0, d <= 2048). */
+int m2f_embed_layernorm(int T, int d, const int64_t* input_ids, const int64_t* position_ids, const float* word_emb,
+                        const float* pos_emb, const float* type_emb_row0, const float* gamma, const float* beta, float eps,
+                        float* out, int ld_out, m2f_stream_t stream);
+
+/* Token-level multi-head self-attention, forward only, any sequence length S (RobertaSelfAttention in eval mode):
+ * q/k/v rows are tokens t = b*S + i, head h in columns [h*hd, (h+1)*hd), hd <= 128; key_pad [B, S] (1 = padded key,
+ * nullable); softmax(q k^T / sqrt(hd) + mask) v with an online softmax over 64-key blocks. */
+int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                           const uint8_t* key_pad, float* out, int ldo, m2f_stream_t stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the plan launches) ---------- */
 /* C[M,N] = epilogue(A x B); layout 0: C = A[M,K] B[N,K]^T (nn.Linear forward), 1: C = A[M,K] B[K,N]
  * (input gradient), 2: C = A[K,M]^T B[K,N] (weight gradient; bias_grad[M] = column sums of A).
@@ -131,7 +153,7 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1,
              const float* b0, int ldb0, const float* b1, int ldb1,
              float* c, int ldc, const float* bias, const float* res, int ldres,
              const float* gate, int ldgate, float gate_scale, float* bias_grad,
-             int relu_a, int relu_b, int relu_out, int accumulate,
+             int relu_a, int relu_b, int relu_out /* 0 none, 1 ReLU, 2 exact GELU */, int accumulate,
              uint32_t drop_site, float drop_p, const uint32_t* rng_state, int tile,
              float* splitk_ws, uint32_t* splitk_tickets, int splitk_max_tiles,
              const uint16_t* a0_bf16, int lda0_bf16, const uint16_t* a1_bf16, int lda1_bf16,

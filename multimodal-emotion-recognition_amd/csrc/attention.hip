@@ -422,6 +422,150 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     }
 }
 
+// ---- long-sequence forward (token-level self-attention of the in-loop text encoder) ------------------------
+// One workgroup = 64 queries of one (sequence, head), wave w owns queries 16w..16w+15.  Keys / values stream through LDS in
+// blocks of 64 with an online softmax (running max / sum per query, accumulators rescaled per block), so any S fits.
+// Same MFMA orientation as the dialogue kernel: S^T = K Q^T puts, for query (lane & 15), four keys per 16-key tile in the
+// accumulator, which is exactly the A operand of the P V product; the O accumulator holds query 4*(lane>>4)+r, so the
+// per-query rescale factors are fetched across lanes with four shuffles per block.  Inference only (no probabilities kept).
+__global__ __launch_bounds__(NTHR) void m2f_attn_long_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, int ldq, int ldk, int ldv,
+                                                                const uint8_t* __restrict__ key_pad, float* __restrict__ out,
+                                                                int ldo, int S, int H, int hd, ShadowMap sh) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int b = (int)blockIdx.y / H, h = (int)blockIdx.y - b * H;
+    const int q0 = (int)blockIdx.x * 64;
+    const int W = (hd + 15) & ~15, ld = W + 2, CT = W >> 4;
+    float* Qs = sm;
+    float* Ks = Qs + 64 * ld;
+    float* Vs = Ks + 64 * ld;
+    const size_t tok0 = (size_t)b * S;
+    const float* qg = q + (tok0 + q0) * ldq + h * hd;
+    const int nq = S - q0 < 64 ? S - q0 : 64;
+    const bool fast = slab_fast_ok(qg, ldq, hd, 64, W) && slab_fast_ok(k + tok0 * ldk + h * hd, ldk, hd, 64, W) &&
+                      slab_fast_ok(v + tok0 * ldv + h * hd, ldv, hd, 64, W);
+    SlabGeom G;
+    if (fast) {
+        slab_geom(G, nq, hd, 64, W, ld, tid);
+        SlabRegs rq;
+        slab_issue(rq, G, qg, ldq);
+        slab_commit(rq, G, Qs);
+    } else {
+        load_slab(Qs, ld, 64, W, qg, ldq, nq, hd, tid);
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int ksteps = (hd + 3) >> 2;
+    float m_run = -INFINITY, l_run = 0.f;                       // of query 16*wv + l15 (replicated over lg)
+    f32x4 o[8];                                                 // O[query 16*wv + 4*lg + r][c = 16*ct + l15]
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i = 16 * wv + l15;                                // this lane's query row (block-local)
+
+    for (int kb = 0; kb < S; kb += 64) {
+        const int nk = S - kb < 64 ? S - kb : 64;
+        __syncthreads();                                        // previous block's K / V fully consumed (and Q committed)
+        const float* kg = k + (tok0 + kb) * ldk + h * hd;
+        const float* vg = v + (tok0 + kb) * ldv + h * hd;
+        const unsigned char kp = key_pad ? key_pad[tok0 + kb + (lane < nk ? lane : 0)] : (unsigned char)0;
+        if (fast) {
+            SlabGeom Gk;
+            slab_geom(Gk, nk, hd, 64, W, ld, tid);
+            SlabRegs rk, rv;
+            slab_issue(rk, Gk, kg, ldk);
+            slab_issue(rv, Gk, vg, ldv);
+            slab_commit(rk, Gk, Ks);
+            slab_commit(rv, Gk, Vs);
+        } else {
+            load_slab(Ks, ld, 64, W, kg, ldk, nk, hd, tid);
+            load_slab(Vs, ld, 64, W, vg, ldv, nk, hd, tid);
+        }
+        const unsigned long long kvalid = __ballot(lane < nk && kp == 0);
+        __syncthreads();
+
+        f32x4 s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* kp_ = Ks + (16 * jt + l15) * ld + lg;
+            const float* qp = Qs + i * ld + lg;
+            int ks = 0;
+            for (; ks + 1 < ksteps; ks += 2) {
+                acc0 = mfma4(kp_[4 * ks], qp[4 * ks], acc0);
+                acc1 = mfma4(kp_[4 * ks + 4], qp[4 * ks + 4], acc1);
+            }
+            if (ks < ksteps) acc0 = mfma4(kp_[4 * ks], qp[4 * ks], acc0);
+            s[jt] = acc0 + acc1;                                // S[i][j = 16jt + 4lg + r]
+        }
+        float m_blk = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * lg + r;
+                const float x = ((kvalid >> j) & 1ull) ? s[jt][r] * scale : -INFINITY;
+                s[jt][r] = x;
+                m_blk = fmaxf(m_blk, x);
+            }
+        m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 16, 64));
+        m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 32, 64));
+        const float m_new = fmaxf(m_run, m_blk);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);     // exp(-inf) = 0 on the first live block
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (m_new == -INFINITY) ? 0.f : __expf(s[jt][r] - m_new);
+                s[jt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        // rescale the accumulators: row (4*lg + r) of this wave's 16 queries has its alpha in lanes with l15 == 4*lg + r
+        float a4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a4[r] = __shfl(alpha, 4 * lg + r, 64);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {                        // static indices keep o[] in registers
+            if (ct >= CT) break;
+            f32x4 acc = o[ct];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= a4[r];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const float* vp = Vs + (16 * jt + 4 * lg) * ld + 16 * ct + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mfma4(s[jt][r], vp[r * ld], acc);
+            }
+            o[ct] = acc;
+        }
+    }
+    float inv4[4];
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv4[r] = __shfl(inv, 4 * lg + r, 64);
+    uint16_t* out16 = m2f_shadow_of(sh, out);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        if (ct >= CT) break;
+        const int c = 16 * ct + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int io = q0 + 16 * wv + 4 * lg + r;
+            if (io < S && c < hd) {
+                const size_t idx = (tok0 + io) * ldo + h * hd + c;
+                const float val = o[ct][r] * inv4[r];
+                out[idx] = val;
+                if (out16) out16[idx] = m2f_bf16_bits(val);
+            }
+        }
+    }
+}
+
 template <bool BWD>
 hipError_t launch(AttnBatch& ab, hipStream_t stream) {
     if (ab.count <= 0 || ab.count > M2F_ATTN_MAX_PROBLEMS || ab.L < 1 || ab.L > 64) return hipErrorInvalidValue;
@@ -466,6 +610,21 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
 size_t m2f_attn_probs_elems(int B, int H, int L) {
     const size_t Lp = 16 * ((L + 15) / 16);
     return (size_t)B * H * Lp * Lp;
+}
+hipError_t m2f_launch_attn_long_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const uint8_t* key_pad, float* out, int ldo, int B, int S, int H, int hd, ShadowMap sh,
+                                    hipStream_t stream) {
+    if (B < 1 || S < 1 || H < 1 || hd < 1 || hd > 128) return hipErrorInvalidValue;
+    const int W = (hd + 15) & ~15;
+    const size_t lds = (size_t)3 * 64 * (W + 2) * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2f_attn_long_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(m2f_attn_long_fwd_kernel, dim3((S + 63) / 64, B * H), dim3(NTHR), lds, stream, q, k, v, ldq, ldk, ldv,
+                       key_pad, out, ldo, S, H, hd, sh);
+    return hipGetLastError();
 }
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream) { return launch<false>(ab, stream); }
 hipError_t m2f_launch_attn_bwd(AttnBatch& ab, hipStream_t stream) { return launch<true>(ab, stream); }

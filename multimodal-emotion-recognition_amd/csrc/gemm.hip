@@ -225,7 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
     char* __restrict__ C16 = reinterpret_cast<char*>(m2f_shadow_of(gb.sh, P.c));
     const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
     const float gscale = P.gate_scale;
-    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
+    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM, gelu_out = flags & GF_GELU_OUT;
     const uint32_t site = P.drop_site;
     uint32_t key = 0;
     if (site) key = m2f_site_key(gb.rng, site);
@@ -298,6 +298,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
                 float x = acc[i][j][r] + bv;
                 if (relu_out) x = fmaxf(x, 0.f);
                 v[r] = x;
+            }
+            if (gelu_out) {                                     // block-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
             }
             if (site) {
 #pragma unroll

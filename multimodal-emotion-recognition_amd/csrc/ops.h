@@ -19,7 +19,8 @@ enum { M2F_PREC_F32 = 0, M2F_PREC_BF16 = 1 };
 enum { M2F_LAYOUT_NT = 0, M2F_LAYOUT_NN = 1, M2F_LAYOUT_TN = 2 };   // fwd / dgrad / wgrad
 enum {
     GF_RELU_A = 1, GF_RELU_B = 2, GF_RELU_OUT = 4, GF_ACCUM = 8,
-    GF_VEC_A = 16, GF_VEC_B = 32     // set by the launcher when 16-byte loads are legal
+    GF_VEC_A = 16, GF_VEC_B = 32,    // set by the launcher when 16-byte loads are legal
+    GF_GELU_OUT = 64                 // exact (erf) GELU instead of ReLU in the epilogue (RoBERTa's intermediate.dense)
 };
 
 struct GemmOperand {
@@ -122,6 +123,11 @@ struct AttnBatch {
     int bwd_fast;              // set by the launcher: LDS holds the fifth (O) slab of the one-round-trip backward path
 };
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
+// Long-sequence forward (S unbounded, hd <= 128): token-level self-attention of the in-loop text encoder (inference).
+// q/k/v rows are token-major (token t = b*S + i), head h in columns [h*hd, (h+1)*hd); key_pad [B, S] (1 = padded, nullable).
+hipError_t m2f_launch_attn_long_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const uint8_t* key_pad, float* out, int ldo, int B, int S, int H, int hd, ShadowMap sh,
+                                    hipStream_t stream);
 hipError_t m2f_launch_attn_bwd(AttnBatch& ab, hipStream_t stream);
 size_t m2f_attn_probs_elems(int B, int H, int L);
 
@@ -206,6 +212,11 @@ struct GatherArgs {
     float* text_out; float* audio_out; uint8_t* key_pad; int64_t* labels;
 };
 hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream);
+
+// RoBERTa embeddings + LayerNorm (in-loop text encoder): out[t] = LN(word[ids[t]] + pos[pos_ids[t]] + type0)
+hipError_t m2f_launch_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                               const float* gamma, const float* beta, float eps, float* out, int ld, int T, int d, ShadowMap sh,
+                               hipStream_t stream);
 
 // in-place: x[t, c] *= keep(site, t*d + c) / (1 - p)
 hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,

@@ -1246,6 +1246,15 @@ int m2f_adam_step_g16(float* params, const uint16_t* grads_bf16, float* exp_avg,
 }
 
 // ---- kernel-level entry points -----------------------------------------------------------------------
+// Optional bf16 shadow map for the kernel-level entry points (the plans carry their own): outputs that lie inside
+// [ws_base, ws_base + floats) are also written as bf16 at the same element index of `shadow`.
+static thread_local ShadowMap g_sh = {nullptr, nullptr, 0};
+int m2f_set_shadow_map(const float* ws_base, uint16_t* shadow, int64_t floats) {
+    if ((ws_base == nullptr) != (shadow == nullptr) || floats < 0) return fail("m2f_set_shadow_map: base / shadow must both be set or both be NULL");
+    g_sh = {ws_base, shadow, (size_t)floats};
+    return 0;
+}
+
 static void drop_params(float p, uint32_t* thresh, float* scale) {
     *thresh = (uint32_t)std::min(4294967295.0, std::floor((double)p * 4294967296.0));
     *scale = 1.0f / (1.0f - p);
@@ -1264,11 +1273,12 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
     if (K1 > 0) gp_seg2(p, a1, lda1, b1, ldb1, K1);
     p.bias = bias; p.res = res; p.ldres = ldres; p.gate = gate; p.ldgate = ldgate; p.gate_scale = gate_scale;
     p.bias_grad = bias_grad; p.drop_site = drop_site;
-    p.flags = (relu_a ? GF_RELU_A : 0) | (relu_b ? GF_RELU_B : 0) | (relu_out ? GF_RELU_OUT : 0) | (accumulate ? GF_ACCUM : 0);
+    p.flags = (relu_a ? GF_RELU_A : 0) | (relu_b ? GF_RELU_B : 0) | (relu_out == 1 ? GF_RELU_OUT : 0) |
+              (relu_out == 2 ? GF_GELU_OUT : 0) | (accumulate ? GF_ACCUM : 0);
     p.a.q[0] = a0q; p.a.ldq[0] = ldaq0; p.a.q[1] = a1q; p.a.ldq[1] = ldaq1;
     p.b.q[0] = b0q; p.b.ldq[0] = ldbq0; p.b.q[1] = b1q; p.b.ldq[1] = ldbq1;
     p.a.qt[0] = p.a.qt[1] = p.b.qt[0] = p.b.qt[1] = nullptr;
-    gb.pr[0] = p; gb.count = 1; gb.rng = rng_state;
+    gb.pr[0] = p; gb.count = 1; gb.rng = rng_state; gb.sh = g_sh;
     gb.splitk_ws = splitk_ws; gb.splitk_cnt = splitk_tickets; gb.splitk_max_tiles = splitk_ws && splitk_tickets ? splitk_max_tiles : 0;
     if (drop_site) drop_params(drop_p, &gb.drop_thresh, &gb.drop_scale);
     M2F_HIP(m2f_launch_gemm(gb, precision, layout, tile, static_cast<hipStream_t>(stream)));
@@ -1317,8 +1327,22 @@ int m2f_layernorm_fwd(int T, int d, const float* x, const float* gamma, const fl
     memset(&lb, 0, sizeof(lb));
     LnProblem& p = lb.pr[0];
     p.x = x; p.gamma = gamma; p.beta = beta; p.res = res; p.out = out; p.stats = stats; p.d = d;
-    lb.count = 1; lb.T = T; lb.eps = eps; lb.drop_scale = 1.f;
+    lb.count = 1; lb.T = T; lb.eps = eps; lb.drop_scale = 1.f; lb.sh = g_sh;
     M2F_HIP(m2f_launch_ln_fwd(lb, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_embed_layernorm(int T, int d, const int64_t* input_ids, const int64_t* position_ids, const float* word_emb,
+                        const float* pos_emb, const float* type_emb_row0, const float* gamma, const float* beta, float eps,
+                        float* out, int ld_out, m2f_stream_t stream) {
+    M2F_HIP(m2f_launch_embed_ln(input_ids, position_ids, word_emb, pos_emb, type_emb_row0, gamma, beta, eps, out, ld_out, T, d, g_sh,
+                                static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                           const uint8_t* key_pad, float* out, int ldo, m2f_stream_t stream) {
+    M2F_HIP(m2f_launch_attn_long_fwd(q, ldq, k, ldk, v, ldv, key_pad, out, ldo, B, S, H, hd, g_sh, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

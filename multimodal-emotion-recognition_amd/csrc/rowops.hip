@@ -648,6 +648,74 @@ hipError_t m2f_launch_cast(const CastBatch& cb, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// RoBERTa embeddings (transformers RobertaEmbeddings.forward, used by the reference at
+// src/feature_extractors/text/model.py:16,19): LayerNorm(word[ids] + position[pos_ids] + token_type[0]), one wavefront per
+// token, d <= 2048 (d % 4 == 0), values in registers.
+__global__ __launch_bounds__(256) void m2f_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float* __restrict__ out,
+                                                           int ld, int T, int d, ShadowMap sh) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* w = word + (size_t)ids[t] * d;
+    const float* p = pos + (size_t)pos_ids[t] * d;
+    f32x4 x[8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < d) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(w + c), b = *reinterpret_cast<const f32x4*>(p + c);
+            const f32x4 ty = *reinterpret_cast<const f32x4*>(type0 + c);
+            x[j] = a + b + ty;
+            s1 += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+        } else {
+            x[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = m2f_wave_sum(s1) / (float)d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dv = x[j][e] - mean; s2 += dv * dv; }
+        }
+    }
+    const float rstd = rsqrtf(m2f_wave_sum(s2) / (float)d + eps);
+    float* o = out + (size_t)t * ld;
+    uint16_t* o16 = m2f_shadow_of(sh, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (x[j][e] - mean) * rstd * g[e] + be[e];
+            *reinterpret_cast<f32x4*>(o + c) = y;
+            if (o16) {
+                uint2 h;
+                h.x = (uint32_t)m2f_bf16_bits(y[0]) | ((uint32_t)m2f_bf16_bits(y[1]) << 16);
+                h.y = (uint32_t)m2f_bf16_bits(y[2]) | ((uint32_t)m2f_bf16_bits(y[3]) << 16);
+                *reinterpret_cast<uint2*>(o16 + c) = h;
+            }
+        }
+    }
+}
+
+hipError_t m2f_launch_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                               const float* gamma, const float* beta, float eps, float* out, int ld, int T, int d, ShadowMap sh,
+                               hipStream_t stream) {
+    if (T < 1 || d < 4 || d > 2048 || (d & 3) || (ld & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(m2f_embed_ln_kernel, dim3(m2f_cdiv(T, 4)), dim3(256), 0, stream, ids, pos_ids, word, pos, type0, gamma, beta,
+                       eps, out, ld, T, d, sh);
+    return hipGetLastError();
+}
+
 hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream) {
     if (a.T < 1 || !a.rows) return hipErrorInvalidValue;
     hipLaunchKernelGGL(m2f_gather_kernel, dim3(m2f_cdiv(a.T, 4)), dim3(256), 0, stream, a);

@@ -1,0 +1,78 @@
+"""GPU parity of the in-loop text encoder: RobertaEncoder on the HIP kernels vs the fixtures written by the
+real transformers.RobertaModel and vs the live CPU oracle.  fp32 mode: 1e-4 on hidden states of O(1) magnitude; bf16 mode
+(bf16 GEMM operands, fp32 accumulate, fp32 attention / LayerNorm / GELU): 6e-2 absolute, stated here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth_roberta as SR
+import mer_amd  # noqa: F401
+from mer_amd.roberta import RobertaEncoder
+from oracle import roberta_oracle as RO
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(c, precision):
+    m = RobertaEncoder(c, precision=precision)
+    m.load_state_dict(SR.make_state_dict(c))
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", list(SR.CASES))
+def test_fp32_matches_transformers_fixture_and_oracle(golden_dir, name):
+    c, B, S, lengths = SR.CASES[name]
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    ids, mask = SR.make_batch(c, B, S, lengths)
+    m = _enc(c, "fp32")
+    hid = m(ids.cuda(), mask.cuda()).cpu()
+    assert np.abs(hid[:, 0, :].numpy() - fx["cls"]).max() < 1e-4
+    last = np.stack([hid[b, n - 1].numpy() for b, n in enumerate(lengths)])
+    assert np.abs(last - fx["hidden_last_valid"]).max() < 1e-4
+    ref = RO.forward(SR.make_state_dict(c), c, ids, mask)
+    assert (hid - ref)[mask.bool()].abs().max().item() < 1e-4
+    cls = m.cls_embeddings(ids.cuda(), mask.cuda()).cpu()
+    assert torch.equal(cls, hid[:, 0, :])
+
+
+@pytest.mark.parametrize("name", ["roberta_tiny", "roberta_three_blocks", "roberta_base_width"])
+def test_bf16_within_stated_tolerance(golden_dir, name):
+    c, B, S, lengths = SR.CASES[name]
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    ids, mask = SR.make_batch(c, B, S, lengths)
+    hid = _enc(c, "bf16")(ids.cuda(), mask.cuda()).cpu()
+    err = np.abs(hid[:, 0, :].numpy() - fx["cls"])
+    assert err.max() < 6e-2 and err.mean() < 1e-2, (err.max(), err.mean())
+
+
+def test_pad_contents_and_batch_composition_do_not_matter():
+    """Valid tokens of a sequence depend neither on what sits in its padded slots nor on the other sequences."""
+    c, B, S, lengths = SR.CASES["roberta_two_blocks"]
+    ids, mask = SR.make_batch(c, B, S, lengths)
+    m = _enc(c, "fp32")
+    hid = m(ids.cuda(), mask.cuda()).cpu()
+    n1 = lengths[1]
+    single = m(ids[1:2, :n1].contiguous().cuda(), mask[1:2, :n1].contiguous().cuda()).cpu()
+    assert (single[0] - hid[1, :n1]).abs().max().item() < 1e-5
+    assert torch.equal(m(ids.cuda(), mask.cuda()).cpu(), hid)          # replay on the cached workspace: bit-identical
+
+
+def test_text_encoder_feeds_the_fusion_model():
+    """BASELINE C5 data flow: token ids -> RobertaEncoder [CLS] rows -> M2FNet text input."""
+    import synth
+    from mer_amd.model import M2FNet
+    c, B, S, lengths = SR.CASES["roberta_tiny"]                      # hidden 64 == d_text of the tiny M2FNet cases
+    cfg, Bm, Lm, mlens, kind = synth.CASES["tiny_ragged"]
+    n_utt = Bm * Lm
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, c["vocab_size"], (n_utt, 12), generator=g)
+    ids[:, 0] = 0
+    enc = _enc(c, "fp32")
+    text = enc.cls_embeddings(ids.cuda()).view(Bm, Lm, -1)
+    _, audio, key_pad, _ = synth.make_inputs(cfg, Bm, Lm, mlens, kind)
+    model = M2FNet(cfg).cuda().eval()
+    with torch.inference_mode():
+        logits = model(text, audio.cuda(), key_pad.cuda())
+    assert logits.shape == (Bm, Lm, 7) and torch.isfinite(logits[~key_pad.cuda()]).all()

@@ -1,0 +1,57 @@
+"""Secondary benchmark (SURVEY 8-f4 / BASELINE C5): forward of the in-loop text encoder (RoBERTa geometry, random weights -
+the pretrained ones cannot be fetched offline) for the utterances of one M2FNet batch.  Prints one JSON line.
+usage: python tools/bench_text_encoder.py [--model base|large] [--utterances 512] [--seq 64] [--dtype bf16|fp32] [--steps 10]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch  # noqa: E402
+import mer_amd  # noqa: E402,F401
+from mer_amd.roberta import RobertaEncoder  # noqa: E402
+
+GEOM = {"base": dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072),
+        "large": dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="large", choices=sorted(GEOM))
+    ap.add_argument("--utterances", type=int, default=512)
+    ap.add_argument("--seq", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    cfg = dict(GEOM[a.model], vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+               layer_norm_eps=1e-5, hidden_act="gelu")
+    torch.manual_seed(0)
+    enc = RobertaEncoder(cfg, precision=a.dtype).cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, cfg["vocab_size"], (a.utterances, a.seq), generator=g)
+    ids[:, 0] = 0
+    ids = ids.cuda()
+    for _ in range(a.warmup):
+        enc.cls_embeddings(ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        enc.cls_embeddings(ids)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / a.steps
+    d, F, Lr, H = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"], cfg["num_attention_heads"]
+    T = a.utterances * a.seq
+    gemm = 2.0 * T * (4 * d * d + 2 * d * F) * Lr
+    attn = 4.0 * a.seq * a.seq * (d // H) * a.utterances * H * Lr
+    peak = 2500.0 if a.dtype == "bf16" else 157.3
+    print(json.dumps({"metric": "utterances/sec, in-loop text encoder forward (RoBERTa-%s geometry, random weights)" % a.model,
+                      "value": a.utterances / sec, "unit": "utterances/s", "ms_per_forward": sec * 1e3, "dtype": a.dtype,
+                      "config": {"utterances": a.utterances, "tokens_per_utterance": a.seq, **GEOM[a.model]},
+                      "algorithmic_tflop": (gemm + attn) / 1e12, "achieved_tflops": (gemm + attn) / sec / 1e12,
+                      "frac_of_mfma_peak": (gemm + attn) / sec / 1e12 / peak, "peak_tflops": peak, "data": "synthetic token ids"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: tools/kstats_cmd.sh <tag> <python script + args>  -> rocprofv3 kernel-trace stats of any repo script
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; tag=$1; shift
+mkdir -p $R/gpurun_out/ks_$tag
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$tag -o p -- python3 $R/"$@" > $R/gpurun_out/ks_$tag/out.json 2> $R/gpurun_out/ks_$tag/err.txt
+python3 - $R/gpurun_out/ks_$tag <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/p_kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        print(f"{r['Name'][:86]:86s} n={r['Calls']:>5s} avg={float(r['AverageNs'])/1e3:9.2f} tot_ms={float(r['TotalDurationNs'])/1e6:8.2f} {r['Percentage']}%")
+PY

@@ -95,6 +95,21 @@ def test_gemm_bf16_source_equals_fp32_source(tile, shape):
     _close(r1, r0, 2e-6, "two segments + relu prologue")
 
 
+def test_gemm_large_m_tile_and_gelu_epilogue():
+    """The text encoder's GEMMs: M = utterances x tokens is large enough for the 256x128 tiles (auto-selected at >= 1024 of
+    them), bias + exact-erf GELU epilogue; ragged edges in both dimensions."""
+    M, N, K = 16384 + 37, 2048 + 24, 264
+    a, b = _rand(M, K, seed=21), _rand(N, K, seed=22)
+    bias = _rand(N, seed=23)
+    got = F.gemm(a, b, F.NT, runtime.BF16, bias=bias, relu_out=2, src16=True)
+    pre = a.to(torch.bfloat16).float() @ b.to(torch.bfloat16).float().t() + bias
+    ref = 0.5 * pre * (1.0 + torch.erf(pre / 2.0 ** 0.5))
+    _close(got, ref, 2e-4, "large-M bf16 GEMM + GELU")
+    got32 = F.gemm(a[:300], b[:200], F.NT, runtime.F32, bias=bias[:200], relu_out=2)
+    pre32 = a[:300] @ b[:200].t() + bias[:200]
+    _close(got32, 0.5 * pre32 * (1.0 + torch.erf(pre32 / 2.0 ** 0.5)), 1e-5, "fp32 GEMM + GELU")
+
+
 @pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
 def test_gemm_epilogue_and_segments(prec):
     M, N, K0, K1 = 96, 80, 64, 40

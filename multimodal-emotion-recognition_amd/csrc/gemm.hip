@@ -6,24 +6,22 @@
 // (reference src/model.py:14,18,111-113,123-125,143 and torch's TransformerEncoderLayer internals)
 // in forward, input-gradient and weight-gradient form.
 //
-// Design (MI355X):
-//   * one workgroup = 4 wavefronts (2x2), each wave owns (BM/2)x(BN/2) of the tile as 32x32 MFMA blocks;
-//   * two arithmetic modes sharing one C/D layout:
-//       F32  : v_mfma_f32_32x32x2_f32  (exact fp32, 157 TF peak)   - the 1e-3 parity mode
-//       BF16 : v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 2.5 PF)  - operands rounded to bf16 while
-//              being staged into LDS; everything in HBM stays fp32 (weights are read once per use,
-//              so no shadow copies / cast kernels are needed);
-//   * operands are register-staged (coalesced 16-byte global loads issued one k-tile ahead of the
-//     MFMAs that consume the previous tile) into a double-buffered LDS image laid out for
-//     conflict-free fragment reads:
-//       F32  : [k][row] floats, row stride BR+1 (ds_read_b32, lanes = consecutive rows)
-//       BF16 : [row][k] bf16, row stride 144 B (ds_read_b128; any 16 consecutive rows cover the 64
-//              banks exactly once)
-//   * "grouped": one launch covers several independent problems (text+audio branch, q/k/v of a
-//     fusion layer, split concat) so the 256 CUs see more workgroups per launch and the
-//     launch-latency-bound chain gets shorter;
-//   * the epilogue fuses bias, ReLU, dropout, residual add, ReLU-gate and accumulate; the wgrad form
-//     also emits the bias gradient (column sums of dY) from the tiles it already streams.
+// Design (MI355X) - two kernel families sharing one C/D layout and one fused epilogue:
+//   * F32 mode (the 1e-3 parity mode) and the fallback for operands without bf16 shadows: `m2f_gemm_kernel`, fp32-source.
+//     One workgroup = 4 wavefronts (2x2), each owning (BM/2)x(BN/2) of the tile as 32x32 blocks of
+//     v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak) or, in BF16 mode, v_mfma_f32_32x32x16_bf16 with the operands
+//     rounded to bf16 while being staged.  Register-staged operands (coalesced 16-byte loads one k-tile ahead), LDS images
+//     laid out for conflict-free fragment reads ([k][row] floats with row stride BR+1 | [row][k] bf16 with 272-byte rows).
+//   * BF16 mode proper: `m2f_gemm16_kernel` (+ `_dense_`, `_table_` variants), bf16-SOURCE: every operand also exists as a
+//     bf16 shadow in HBM (half the bytes through the per-CU L1 fill path that bounds these GEMMs).  Workgroups of 8 waves
+//     split into 4 producer waves (global -> register ring of D k-tiles -> LDS) and 4 consumer waves (LDS -> MFMA ->
+//     epilogue); tiles 64x64 (chain launches), 128x128 (weight gradients, persistent walk over a device-resident problem
+//     table) or 256x128 (text encoder); see the comment above gemm16_body.
+//   * "grouped": one launch covers several independent problems (text+audio branch, q/k/v of a fusion layer, split
+//     concat) so the 256 CUs see more workgroups per launch and the launch-latency-bound chain gets shorter;
+//   * the epilogue fuses bias, ReLU / exact GELU, dropout, residual add, ReLU-gate and accumulate (32-bit offsets from
+//     uniform bases, optional terms behind block-uniform branches) and writes the bf16 shadow of C; the row-contiguous
+//     wgrad form also emits the bias gradient (column sums of dY) from the tiles it already streams.
 #include "common.h"
 #include "ops.h"
 #include <cstdlib>

@@ -7,8 +7,9 @@
 //     launch chains are MERGED pairwise into grouped launches (longest-common-subsequence alignment):
 //     half the launches, twice the workgroups per launch on a chip with 256 CUs;
 //   * every weight-gradient GEMM is DEFERRED: with 288 GB of HBM all dY / X operands stay resident, so the
-//     ~100 wgrad problems run as a handful of chip-filling grouped launches after the latency-bound
-//     input-gradient chain instead of being interleaved with it;
+//     ~85 wgrad problems run after the latency-bound input-gradient chain instead of being interleaved with
+//     it - in bf16 mode as ONE persistent launch over a device-resident problem table, fed by one launch that
+//     writes token-transposed bf16 copies of the operands (fp32 mode: a handful of grouped launches);
 //   * torch.cat is never materialised (two-segment GEMM operands), bias/ReLU/dropout/residual/ReLU-gate
 //     live in GEMM epilogues, dropout masks are regenerated from a counter RNG in backward.
 // Math follows the reference: src/model.py:102-145 (M2FNet.forward), :13-20 (FusionAttentionModule),

@@ -211,7 +211,9 @@ struct Stage {
 // Fused epilogue shared by the fp32-source and bf16-source kernels:
 //   +bias[n] -> relu -> dropout(site) -> +res[m,n] -> *(gate[m,n] > 0 ? gate_scale : 0) -> (C += | C =) [-> bf16 shadow of C]
 // Side loads are unconditional (clamped) and issued before the arithmetic; stores are predicated.
-template <int MI, int NI, int BM, int BN>
+// GELU is a COMPILE-TIME variant: carrying the erf expansion (and its constants) in every instantiation doubled the SGPR
+// spills of the chain kernels (24 -> 52) and cost the M2FNet step 3.4 %; only the text encoder's GEMMs use it.
+template <int MI, int NI, int BM, int BN, bool GELU = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmProblem& P, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn) {
     const int M = P.M, N = P.N;
@@ -223,7 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
     char* __restrict__ C16 = reinterpret_cast<char*>(m2f_shadow_of(gb.sh, P.c));
     const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
     const float gscale = P.gate_scale;
-    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM, gelu_out = flags & GF_GELU_OUT;
+    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
     const uint32_t site = P.drop_site;
     uint32_t key = 0;
     if (site) key = m2f_site_key(gb.rng, site);
@@ -297,9 +299,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
                 if (relu_out) x = fmaxf(x, 0.f);
                 v[r] = x;
             }
-            if (gelu_out) {                                     // block-uniform
+            if constexpr (GELU) {
+                if (flags & GF_GELU_OUT) {                      // block-uniform
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                    for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                }
             }
             if (site) {
 #pragma unroll
@@ -352,7 +356,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC>
+template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC, bool GELU = false>
 __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
     using SA = Stage<PREC, A_RC, BM, BK, VEC>;
     using SB = Stage<PREC, B_RC, BN, BK, VEC>;
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(256) void m2f_gemm_kernel(const GemmBatch gb) {
                 }
     }
 
-    gemm_epilogue<MI, NI, BM, BN>(gb, P, acc, m0, n0, lane, wm, wn);
+    gemm_epilogue<MI, NI, BM, BN, GELU>(gb, P, acc, m0, n0, lane, wm, wn);
 }
 
 // =========================================================================================================
@@ -708,7 +712,7 @@ __device__ unsigned long long m2f_dbg[64];
 #else
 #define M2F_TS(slot) do {} while (0)
 #endif
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool TABLE>
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool TABLE, bool GELU = false>
 __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     static_assert(!(A_RC && !B_RC), "layouts: NT, NN, TN");
     constexpr bool TN = A_RC && B_RC;
@@ -907,7 +911,7 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
         }
     }
     M2F_TS(3);
-    gemm_epilogue<MI, NI, BM, BN>(gb, P, acc, m0, n0, lane, wm, wn);
+    gemm_epilogue<MI, NI, BM, BN, GELU>(gb, P, acc, m0, n0, lane, wm, wn);
     M2F_TS(4);
   }
 }
@@ -915,9 +919,9 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
 // Two register budgets of the same body.  "wide": up to 256 VGPRs, one workgroup (8 waves) per CU - the launches with
 // at most one tile per CU, where a deep load ring is what matters.  "dense": at most 128 VGPRs (4 waves per SIMD), two
 // workgroups per CU with a shallower ring each - the launches with more tiles than CUs.
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool GELU = false>
 __global__ __launch_bounds__(512) void m2f_gemm16_kernel(const GemmBatch gb) {
-    gemm16_body<A_RC, B_RC, BM, BN, BK, D, false>(gb);
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D, false, GELU>(gb);
 }
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void m2f_gemm16_dense_kernel(const GemmBatch gb) {
@@ -933,15 +937,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     gemm16_body<A_RC, B_RC, BM, BN, BK, D, true>(gb);
 }
 
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false>
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false, bool GELU = false>
 hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
     constexpr int lds = 2 * (A_RC ? Stage16RC<BM, BK>::LDS_BYTES : Stage16KC<BM, BK>::LDS_BYTES) +
                         2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES) + (BK / 8) * BM * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!DENSE || 2 * lds <= 160 * 1024, "two workgroups per CU");
     void (*kern)(const GemmBatch);
+    static_assert(!(DENSE && GELU), "the GELU epilogue exists for the wide forward-form kernels only");
     if constexpr (DENSE) kern = m2f_gemm16_dense_kernel<A_RC, B_RC, BM, BN, BK, D>;
-    else kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D>;
+    else kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D, GELU>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -954,13 +959,13 @@ hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream
     return hipGetLastError();
 }
 
-template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC>
+template <int PREC, bool A_RC, bool B_RC, int BM, int BN, int BK, bool VEC, bool GELU = false>
 hipError_t launch_cfg(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
     using SA = Stage<PREC, A_RC, BM, BK, VEC>;
     using SB = Stage<PREC, B_RC, BN, BK, VEC>;
     constexpr int lds = 2 * SA::LDS_BYTES + 2 * SB::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = m2f_gemm_kernel<PREC, A_RC, B_RC, BM, BN, BK, VEC>;
+    auto kern = m2f_gemm_kernel<PREC, A_RC, B_RC, BM, BN, BK, VEC, GELU>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1024,6 +1029,17 @@ hipError_t launch_tile(GemmBatch& gb, int tile, hipStream_t stream) {
     bool vec = true;
     for (int i = 0; i < gb.count; ++i)
         vec = vec && (gb.pr[i].flags & GF_VEC_A) && (gb.pr[i].flags & GF_VEC_B);
+    if constexpr (!A_RC && !B_RC) {                             // GELU epilogue: forward form only (text encoder)
+        bool gelu = false;
+        for (int i = 0; i < gb.count; ++i) gelu = gelu || (gb.pr[i].flags & GF_GELU_OUT);
+        if (gelu) {
+            if (tile == 128)
+                return vec ? launch_cfg<PREC, false, false, 128, 128, BK128, true, true>(gb, t, stream)
+                           : launch_cfg<PREC, false, false, 128, 128, BK128, false, true>(gb, t, stream);
+            return vec ? launch_cfg<PREC, false, false, 64, 64, BK64, true, true>(gb, t, stream)
+                       : launch_cfg<PREC, false, false, 64, 64, BK64, false, true>(gb, t, stream);
+        }
+    }
     if (tile == 128)
         return vec ? launch_cfg<PREC, A_RC, B_RC, 128, 128, BK128, true>(gb, t, stream)
                    : launch_cfg<PREC, A_RC, B_RC, 128, 128, BK128, false>(gb, t, stream);
@@ -1057,6 +1073,13 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
     if (t == 0) return hipSuccess;
     constexpr int D64 = (!A_RC && B_RC) ? 3 : 4;     // dgrad holds a 32-register patch per set -> one stage less
     if constexpr (!A_RC && !B_RC) {
+        bool gelu = false;
+        for (int i = 0; i < gb.count; ++i) gelu = gelu || (gb.pr[i].flags & GF_GELU_OUT);
+        if (gelu) {                                              // text encoder (forward form only): own instantiations
+            if (tile == 256) return launch_cfg16<false, false, 256, 128, 64, 2, false, true>(gb, t, stream);
+            if (tile == 128) return launch_cfg16<false, false, 128, 128, 64, 3, false, true>(gb, t, stream);
+            return launch_cfg16<false, false, 64, 64, 128, 4, false, true>(gb, t, stream);
+        }
         if (tile == 256) return launch_cfg16<false, false, 256, 128, 64, 2>(gb, t, stream);
     }
     if (tile == 128) return launch_cfg16<A_RC, B_RC, 128, 128, 64, 3>(gb, t, stream);

@@ -142,6 +142,8 @@ class RobertaEncoder(torch.nn.Module):
         if self._packed is None or self._packed_versions != self._versions():
             self._pack()
         B, S = input_ids.shape
+        if S + self.pad_id + 1 > self.max_pos:
+            raise ValueError(f"sequence length {S} needs position ids up to {S + self.pad_id}, but max_position_embeddings = {self.max_pos}")
         dev = input_ids.device
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)

@@ -849,7 +849,10 @@ int build_plan(m2f_plan& P, char* ws_base) {
     std::vector<uint16_t> tblock;
     std::vector<GemmProblem> tprobs;
     std::vector<uint16_t> tile_prob;
-    bool table_ok = P.train && !bld.wgrads.empty();
+    // M2F_WGRAD_TABLE=0 (read when a plan is built) keeps the grouped row-contiguous launches in bf16 mode too: the parity
+    // tests compare the two weight-gradient paths against each other
+    const char* wg_env = getenv("M2F_WGRAD_TABLE");
+    bool table_ok = P.train && !bld.wgrads.empty() && !(wg_env && wg_env[0] == '0');
     const int ldt = (T + 7) & ~7;
     if (table_ok) {
         auto item_of = [&](const float* src, int ld, int F, int relu) {

@@ -175,6 +175,40 @@ def test_bf16_mode_within_stated_tolerance(golden_dir, name):
             assert abs(gn - ref_norm) <= 0.06 * ref_norm, (k, gn, ref_norm)
 
 
+def _train_grads(cfg, prec, batch):
+    m = _model(cfg, precision=prec, train=True)
+    m.train_step(*[t.cuda() for t in batch], use_graph=False)
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("name", ["tiny_ragged", "tiny_shared_norm", "c2_slice"])
+def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monkeypatch):
+    """bf16 mode has two weight-gradient paths: token-transposed copies + ONE persistent table GEMM (bias gradients =
+    column sums made by the transposing launch), and the grouped row-contiguous launches (M2F_WGRAD_TABLE=0).  Same operands,
+    same rounding points for the matrices, different summation order (bias gradients: the table path sums the fp32 dY, the
+    row-contiguous path its bf16 copy): every gradient must agree to 5e-3 of the tensor's largest magnitude.
+    Against the fp32 mode both sit at ~10 % relative L2 on the deepest tensors (bf16 operand rounding through the network),
+    checked with 20 % (a mis-routed tensor or a transposition error is off by ~100 %)."""
+    fx = _load(golden_dir, name)
+    cfg, text, audio, key_pad, emotion = _inputs(name, fx)
+    batch = (text, audio, key_pad, emotion)
+    g_table = _train_grads(cfg, "bf16", batch)
+    monkeypatch.setenv("M2F_WGRAD_TABLE", "0")
+    g_tn = _train_grads(cfg, "bf16", batch)
+    monkeypatch.delenv("M2F_WGRAD_TABLE")
+    g32 = _train_grads(cfg, "fp32", batch)
+    checked = 0
+    for k, ref in g32.items():
+        scale = ref.abs().max().item()
+        if scale < 1e-6:
+            continue                                   # structurally zero gradients (e.g. key biases: softmax shift invariance)
+        assert (g_table[k] - g_tn[k]).abs().max().item() <= 5e-3 * scale, k
+        d = g_table[k] - ref
+        assert d.double().norm().item() <= 0.20 * ref.double().norm().item(), (k, d.norm().item(), ref.norm().item())
+        checked += 1
+    assert checked >= 20
+
+
 def test_live_oracle_full_size_properties():
     """BASELINE config C2' shape (B=32, L=16, 768/768/768) at reduced depth, checked live against the oracle,
     plus size-independent properties at full size: pad-content independence and dialogue independence."""

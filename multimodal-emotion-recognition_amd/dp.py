@@ -83,6 +83,15 @@ class GradReducer:
         # bf16 exchange: buckets over the parameter part only
         pedges = [round(i * n_params / n_buckets / 64) * 64 for i in range(n_buckets)] + [n_params]
         self.param_chunks = [(a, b) for a, b in zip(pedges[:-1], pedges[1:]) if b > a]
+        if exchange == "bf16" and dist.is_initialized():
+            # probe once, on every rank alike: a backend without bf16 reductions falls back to the exact fp32 exchange
+            try:
+                probe = torch.zeros(64, dtype=torch.bfloat16, device=buf.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=group)
+            except (RuntimeError, ValueError, TypeError) as e:          # pragma: no cover - depends on the backend build
+                import sys
+                print(f"mer_amd.dp: bf16 all-reduce unavailable ({e}); using the fp32 gradient exchange", file=sys.stderr)
+                self.exchange = exchange = "fp32"
         self.buf16 = torch.empty(n_params, dtype=torch.bfloat16, device=buf.device) if exchange == "bf16" else None
         self._work = []
 

@@ -220,7 +220,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B,
                        "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
-                       "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({exchange})" if world > 1 else "") + " + fused Adam",
+                       "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({stepper.reducer.exchange})" if world > 1 else "") + " + fused Adam",
                        "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                        "launches_per_step": plan.num_launches()},
             "loss": loss,

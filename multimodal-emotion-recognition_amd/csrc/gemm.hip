@@ -25,6 +25,7 @@
 #include "common.h"
 #include "ops.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -752,19 +753,29 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     else {
 #pragma unroll
         for (int i = 1; i < M2F_GEMM_MAX_PROBLEMS; ++i)
-            if (i < gb.count && bpos >= gb.pr[i].tile_begin) pi = i;
+            if (bpos >= gb.tb[i]) pi = i;                        // unused slots hold INT_MAX
     }
-    const GemmProblem& P = TABLE ? gb.table[pi] : gb.pr[pi];
-    const int M = P.M, N = P.N;
-    const int tl = bpos - P.tile_begin;
+    const GemmProblem& P = TABLE ? gb.table[pi] : gb.pr[pi];     // epilogue terms (consumers, off the critical path)
+    // descriptors the first loads depend on: from the compact header (grouped launches) or the device table
+    GemmHot Hh;
+    if constexpr (TABLE) {
+        Hh.aq[0] = P.a.q[0]; Hh.aq[1] = P.a.q[1]; Hh.bq[0] = P.b.q[0]; Hh.bq[1] = P.b.q[1];
+        Hh.M = P.M; Hh.N = P.N; Hh.k[0] = P.a.k[0]; Hh.k[1] = P.a.k[1];
+        Hh.ldaq[0] = P.a.ldq[0]; Hh.ldaq[1] = P.a.ldq[1]; Hh.ldbq[0] = P.b.ldq[0]; Hh.ldbq[1] = P.b.ldq[1];
+        Hh.flags = P.flags; Hh.tile_begin = P.tile_begin; Hh.has_bias_grad = P.bias_grad != nullptr;
+    } else {
+        Hh = gb.hot[pi];
+    }
+    const int M = Hh.M, N = Hh.N;
+    const int tl = bpos - Hh.tile_begin;
     const int tiles_m = (M + BM - 1) / BM;
     const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;       // M fastest: neighbours share the B panel
-    const int nk0 = (P.a.k[0] + BK - 1) / BK, nk = nk0 + (P.a.k[1] + BK - 1) / BK;
-    const bool has_bg = TN && P.bias_grad != nullptr && n0 == 0;        // block-uniform
+    const int nk0 = (Hh.k[0] + BK - 1) / BK, nk = nk0 + (Hh.k[1] + BK - 1) / BK;
+    const bool has_bg = TN && Hh.has_bias_grad && n0 == 0;              // block-uniform
 
     if (producer) {
         // ================================ PRODUCER: global -> registers -> LDS ================================
-        const uint32_t flags = P.flags;
+        const uint32_t flags = Hh.flags;
         const bool reluA = flags & GF_RELU_A, reluB = flags & GF_RELU_B;
         struct Set {                   // one register set = this thread's share of one k-tile of both operands
             SAK ak;                    // NT, NN: A
@@ -778,10 +789,10 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
         const bool want_bg = has_bg && !second_half;
         // operand descriptors in SGPRs for the whole k-loop: indexing P.a.q[seg] with a run-time seg makes the compiler
         // re-read the kernarg segment (s_load + lgkmcnt(0)) several times per k-tile, serialised in front of the loads
-        const uint16_t* const aq0 = P.a.q[0]; const uint16_t* const aq1 = P.a.q[1];
-        const uint16_t* const bq0 = P.b.q[0]; const uint16_t* const bq1 = P.b.q[1];
-        const int ak0 = P.a.k[0], ak1 = P.a.k[1];
-        const int ald0 = P.a.ldq[0], ald1 = P.a.ldq[1], bld0 = P.b.ldq[0], bld1 = P.b.ldq[1];
+        const uint16_t* const aq0 = Hh.aq[0]; const uint16_t* const aq1 = Hh.aq[1];
+        const uint16_t* const bq0 = Hh.bq[0]; const uint16_t* const bq1 = Hh.bq[1];
+        const int ak0 = Hh.k[0], ak1 = Hh.k[1];
+        const int ald0 = Hh.ldaq[0], ald1 = Hh.ldaq[1], bld0 = Hh.ldbq[0], bld1 = Hh.ldbq[1];
         auto setup_all = [&](int seg) {
             const int lda = seg ? ald1 : ald0, ldb = seg ? bld1 : bld0;
 #pragma unroll
@@ -951,6 +962,18 @@ hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream
                         2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES) + (BK / 8) * BM * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!DENSE || 2 * lds <= 160 * 1024, "two workgroups per CU");
+    GemmBatch hb = gb;                                          // compact header for the kernel's critical path
+    for (int i = 0; i < M2F_GEMM_MAX_PROBLEMS; ++i) {
+        hb.tb[i] = i < gb.count ? gb.pr[i].tile_begin : 0x7fffffff;
+        GemmHot& h = hb.hot[i];
+        memset(&h, 0, sizeof(h));
+        if (i >= gb.count) continue;
+        const GemmProblem& p = gb.pr[i];
+        h.aq[0] = p.a.q[0]; h.aq[1] = p.a.q[1]; h.bq[0] = p.b.q[0]; h.bq[1] = p.b.q[1];
+        h.M = p.M; h.N = p.N; h.k[0] = p.a.k[0]; h.k[1] = p.a.k[1];
+        h.ldaq[0] = p.a.ldq[0]; h.ldaq[1] = p.a.ldq[1]; h.ldbq[0] = p.b.ldq[0]; h.ldbq[1] = p.b.ldq[1];
+        h.flags = p.flags; h.tile_begin = p.tile_begin; h.has_bias_grad = p.bias_grad != nullptr;
+    }
     void (*kern)(const GemmBatch);
     static_assert(!(DENSE && GELU), "the GELU epilogue exists for the wide forward-form kernels only");
     if constexpr (DENSE) kern = m2f_gemm16_dense_kernel<A_RC, B_RC, BM, BN, BK, D>;
@@ -963,7 +986,7 @@ hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds, stream, gb);
+    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds, stream, hb);
     return hipGetLastError();
 }
 

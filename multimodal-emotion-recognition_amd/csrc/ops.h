@@ -62,7 +62,18 @@ struct GemmProblem {
 };
 
 #define M2F_GEMM_MAX_PROBLEMS 8
+// What a workgroup of the bf16-source kernel needs before it can issue its first load, packed at the FRONT of the kernarg
+// block (filled by the launcher from pr[]): the tile -> problem search reads one 32-byte array instead of eight fields in
+// eight different 256-byte structs, the producer's descriptors sit in 96 contiguous bytes instead of five cache lines of a
+// cold kernarg segment.
+struct GemmHot {
+    const uint16_t* aq[2]; const uint16_t* bq[2];
+    int M, N, k[2], ldaq[2], ldbq[2];
+    uint32_t flags; int tile_begin; int has_bias_grad; int pad_[3];
+};
 struct GemmBatch {
+    int tb[M2F_GEMM_MAX_PROBLEMS];           // tile_begin of problem i (INT_MAX for unused slots)
+    GemmHot hot[M2F_GEMM_MAX_PROBLEMS];
     GemmProblem pr[M2F_GEMM_MAX_PROBLEMS];
     int count;
     const uint32_t* rng;      // dropout RNG state (device), may be null when no problem has drop_site

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_ATTN_MAX_PROBLEMS; ++i)
-        if (i < ab.count && (int)blockIdx.x >= ab.pr[i].block_begin) pi = i;
+        if ((int)blockIdx.x >= ab.bb[i]) pi = i;
     const AttnProblem& P = ab.pr[pi];
     const int H = P.H, hd = P.hd, L = ab.L;
     const int bh = (int)blockIdx.x - P.block_begin;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_ATTN_MAX_PROBLEMS; ++i)
-        if (i < ab.count && (int)blockIdx.x >= ab.pr[i].block_begin) pi = i;
+        if ((int)blockIdx.x >= ab.bb[i]) pi = i;
     const AttnProblem& P = ab.pr[pi];
     const int H = P.H, hd = P.hd, L = ab.L;
     const int bh = (int)blockIdx.x - P.block_begin;
@@ -571,11 +571,13 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
     if (ab.count <= 0 || ab.count > M2F_ATTN_MAX_PROBLEMS || ab.L < 1 || ab.L > 64) return hipErrorInvalidValue;
     const int NT = (ab.L + 15) / 16, Lp = 16 * NT;
     int blocks = 0, maxW = 0;
+    for (int i = 0; i < M2F_ATTN_MAX_PROBLEMS; ++i) ab.bb[i] = 0x7fffffff;
     for (int i = 0; i < ab.count; ++i) {
         AttnProblem& p = ab.pr[i];
         if (p.hd < 1 || p.hd > 256 || p.H < 1) return hipErrorInvalidValue;
         if (p.drop_site && !ab.rng) return hipErrorInvalidValue;
         p.block_begin = blocks;
+        ab.bb[i] = blocks;
         blocks += ab.B * p.H;
         const int W = (p.hd + 15) & ~15;
         if (W > maxW) maxW = W;

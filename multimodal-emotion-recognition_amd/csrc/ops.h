@@ -123,6 +123,7 @@ struct AttnProblem {
 };
 #define M2F_ATTN_MAX_PROBLEMS 4
 struct AttnBatch {
+    int bb[M2F_ATTN_MAX_PROBLEMS];      // block_begin of problem i (INT_MAX for unused slots): one line for the block -> problem search
     AttnProblem pr[M2F_ATTN_MAX_PROBLEMS];
     int count;
     int B, L;
@@ -161,6 +162,7 @@ struct LnProblem {
 };
 #define M2F_LN_MAX_PROBLEMS 4
 struct LnBatch {
+    int bb[M2F_LN_MAX_PROBLEMS];        // block_begin of problem i (INT_MAX for unused slots)
     LnProblem pr[M2F_LN_MAX_PROBLEMS];
     int count;
     int T;

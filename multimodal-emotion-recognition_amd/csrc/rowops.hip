@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_LN_MAX_PROBLEMS; ++i)
-        if (i < lb.count && (int)blockIdx.x >= lb.pr[i].block_begin) pi = i;
+        if ((int)blockIdx.x >= lb.bb[i]) pi = i;
     const LnProblem& P = lb.pr[pi];
     const int d = P.d;
     const int ld = P.ld ? P.ld : d;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < M2F_LN_MAX_PROBLEMS; ++i)
-        if (i < lb.count && (int)blockIdx.x >= lb.pr[i].block_begin) pi = i;
+        if ((int)blockIdx.x >= lb.bb[i]) pi = i;
     const LnProblem& P = lb.pr[pi];
     const int d = P.d;
     const int ld = P.ld ? P.ld : d;
@@ -424,11 +424,13 @@ template <bool BWD>
 hipError_t ln_launch(LnBatch& lb, hipStream_t stream) {
     if (lb.count <= 0 || lb.count > M2F_LN_MAX_PROBLEMS || lb.T <= 0) return hipErrorInvalidValue;
     int blocks = 0, maxd = 0;
+    for (int i = 0; i < M2F_LN_MAX_PROBLEMS; ++i) lb.bb[i] = 0x7fffffff;
     for (int i = 0; i < lb.count; ++i) {
         LnProblem& p = lb.pr[i];
         if (p.d < 1 || p.d > 256 * LN_MAXV_LIMIT) return hipErrorInvalidValue;
         if ((p.drop_site || p.drop_site2) && !lb.rng) return hipErrorInvalidValue;
         p.block_begin = blocks;
+        lb.bb[i] = blocks;
         blocks += m2f_ln_row_blocks(lb.T);
         if (p.d > maxd) maxd = p.d;
     }

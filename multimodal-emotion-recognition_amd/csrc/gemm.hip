@@ -1102,21 +1102,22 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
         t += m2f_cdiv(p.M, tile_m) * p.tiles_n;
     }
     if (t == 0) return hipSuccess;
-    constexpr int D64 = (!A_RC && B_RC) ? 3 : 4;     // dgrad holds a 32-register patch per set -> one stage less
     if constexpr (!A_RC && !B_RC) {
         bool gelu = false;
         for (int i = 0; i < gb.count; ++i) gelu = gelu || (gb.pr[i].flags & GF_GELU_OUT);
         if (gelu) {                                              // text encoder (forward form only): own instantiations
             if (tile == 256) return launch_cfg16<false, false, 256, 128, 64, 2, false, true>(gb, t, stream);
             if (tile == 128) return launch_cfg16<false, false, 128, 128, 64, 3, false, true>(gb, t, stream);
-            return launch_cfg16<false, false, 64, 64, 128, 4, false, true>(gb, t, stream);
+            return launch_cfg16<false, false, 64, 64, 128, 2, false, true>(gb, t, stream);
         }
         if (tile == 256) return launch_cfg16<false, false, 256, 128, 64, 2>(gb, t, stream);
     }
     if (tile == 128) return launch_cfg16<A_RC, B_RC, 128, 128, 64, 3>(gb, t, stream);
-    // (a 6-deep variant that keeps the whole K = 768 in flight was measured: no gain over 4)
-    if (t > 256) return launch_cfg16<A_RC, B_RC, 64, 64, 128, 2, true>(gb, t, stream);      // two workgroups per CU
-    return launch_cfg16<A_RC, B_RC, 64, 64, 128, D64>(gb, t, stream);
+    // ONE 64x64 build for every launch size: ring depth 2 within 128 VGPRs (two workgroups per CU when the launch has more
+    // tiles than CUs).  Deeper rings (4, 6) gain nothing - the vector L1 caps the misses in flight, not the software - and
+    // cost code size: same-box A/B of the whole step, 2.130 (depth 4 + separate 256-VGPR build) -> 2.107 ms; the step
+    // alternates between ~8 kernels, so every kilobyte of code is instruction-cache traffic at each launch.
+    return launch_cfg16<A_RC, B_RC, 64, 64, 128, 2, true>(gb, t, stream);
 }
 
 // can every operand of every problem be staged from its bf16 shadow with 16-byte loads?

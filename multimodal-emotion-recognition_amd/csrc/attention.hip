@@ -30,39 +30,43 @@ constexpr int NWAVE = NTHR / 64;
 __device__ __forceinline__ void load_slab(float* __restrict__ lds, int ld, int Lp, int W,
                                           const float* __restrict__ src, int ldg, int L, int hd, int tid) {
     const int total = Lp * W;
-    for (int base = 0; base < total; base += NTHR * 8) {
-        float x[8];
+#pragma unroll 1
+    for (int base = 0; base < total; base += NTHR * 4) {
+        float x[4];
+        int off[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int e = base + tid + NTHR * u;
             const int r = e / W, c = e - r * W;
             const bool ok = e < total && r < L && c < hd;
+            off[u] = e < total ? r * ld + c : -1;
             x[u] = src[ok ? (size_t)r * ldg + c : (size_t)0];
+            if (!ok) x[u] = 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = base + tid + NTHR * u;
-            const int r = e / W, c = e - r * W;
-            if (e < total) lds[r * ld + c] = (r < L && c < hd) ? x[u] : 0.f;
-        }
+        for (int u = 0; u < 4; ++u)
+            if (off[u] >= 0) lds[off[u]] = x[u];
     }
 }
 
-// Fast form for slabs of at most NTHR*4 float4 whose rows are 16-byte aligned: the (row, column) of each of a thread's
-// (up to) four float4 is worked out ONCE (one integer division) and shared by every slab of the kernel (same L, hd, W),
-// all slabs are issued before the first is committed.
+// Fast form for slabs of at most NTHR*NV float4 whose rows are 16-byte aligned: the (row, column) of each of a thread's
+// (up to) NV float4 is worked out ONCE (one integer division) and shared by every slab of the kernel (same L, hd, W),
+// all slabs are issued before the first is committed.  NV = 2 * (Lp / 16) covers every head dim <= 128, so the generic
+// (scalar, division-heavy) form below only serves unaligned operands; it is kept small on purpose.
+template <int NV>
 struct SlabGeom {
-    int goff_rc[4];      // r * 65536 + c   (r < 64, c < 256)
-    int loff[4];         // r * ld + c  (LDS float offset)
-    bool inb[4];         // element index < total (a slot of this thread exists)
-    bool ok[4];          // ... and lies inside [0, L) x [0, hd)
+    int goff_rc[NV];     // r * 65536 + c   (r < 64, c < 256)
+    int loff[NV];        // r * ld + c  (LDS float offset)
+    bool inb[NV];        // element index < total (a slot of this thread exists)
+    bool ok[NV];         // ... and lies inside [0, L) x [0, hd)
 };
-__device__ __forceinline__ void slab_geom(SlabGeom& G, int L, int hd, int Lp, int W, int ld, int tid) {
+template <int NV>
+__device__ __forceinline__ void slab_geom(SlabGeom<NV>& G, int L, int hd, int Lp, int W, int ld, int tid) {
     const int C4 = W >> 2, total = Lp * C4;
     int r = tid / C4, c4 = tid - r * C4;
     const int dr = NTHR / C4, dc = NTHR - dr * C4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int e = tid + NTHR * u;
         const int c = c4 << 2;
         G.inb[u] = e < total;
@@ -73,21 +77,25 @@ __device__ __forceinline__ void slab_geom(SlabGeom& G, int L, int hd, int Lp, in
         if (c4 >= C4) { c4 -= C4; ++r; }
     }
 }
+template <int NV>
 __device__ __forceinline__ bool slab_fast_ok(const float* src, int ldg, int hd, int Lp, int W) {
-    return ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (Lp * (W >> 2) <= NTHR * 4);
+    return ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (Lp * (W >> 2) <= NTHR * NV);
 }
-struct SlabRegs { f32x4 x[4]; };
-__device__ __forceinline__ void slab_issue(SlabRegs& R, const SlabGeom& G, const float* __restrict__ src, int ldg) {
+template <int NV>
+struct SlabRegs { f32x4 x[NV]; };
+template <int NV>
+__device__ __forceinline__ void slab_issue(SlabRegs<NV>& R, const SlabGeom<NV>& G, const float* __restrict__ src, int ldg) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int r = G.goff_rc[u] >> 16, c = G.goff_rc[u] & 0xFFFF;
         const uint32_t o = G.ok[u] ? (uint32_t)(r * ldg + c) * 4u : 0u;
         R.x[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src) + (size_t)o);
     }
 }
-__device__ __forceinline__ void slab_commit(const SlabRegs& R, const SlabGeom& G, float* __restrict__ lds) {
+template <int NV>
+__device__ __forceinline__ void slab_commit(const SlabRegs<NV>& R, const SlabGeom<NV>& G, float* __restrict__ lds) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NV; ++u) {
         if (G.inb[u]) {
             const bool ok = G.ok[u];
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -124,10 +132,11 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
     const float* kg = P.k + tok0 * P.ldk + h * hd;
     const float* vg = P.v + tok0 * P.ldv + h * hd;
     const unsigned char kpad = ab.key_pad[tok0 + (lane < L ? lane : 0)];
-    if (slab_fast_ok(qg, P.ldq, hd, Lp, W) && slab_fast_ok(kg, P.ldk, hd, Lp, W) && slab_fast_ok(vg, P.ldv, hd, Lp, W)) {
-        SlabGeom G;
+    constexpr int NV = 2 * NT;                                // float4 per thread and slab: covers W <= 128
+    if (slab_fast_ok<NV>(qg, P.ldq, hd, Lp, W) && slab_fast_ok<NV>(kg, P.ldk, hd, Lp, W) && slab_fast_ok<NV>(vg, P.ldv, hd, Lp, W)) {
+        SlabGeom<NV> G;
         slab_geom(G, L, hd, Lp, W, ld, tid);
-        SlabRegs rq, rk, rv;                                  // one round trip for the three operands
+        SlabRegs<NV> rq, rk, rv;                              // one round trip for the three operands
         slab_issue(rq, G, qg, P.ldq);
         slab_issue(rk, G, kg, P.ldk);
         slab_issue(rv, G, vg, P.ldv);
@@ -257,12 +266,13 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     // NT == 1: the saved probabilities this lane needs in both orientations, fetched with everything else
     float px[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 py = {0.f, 0.f, 0.f, 0.f};
-    const bool fast = ab.bwd_fast && slab_fast_ok(qg, P.ldq, hd, Lp, W) && slab_fast_ok(kg, P.ldk, hd, Lp, W) &&
-                      slab_fast_ok(vg, P.ldv, hd, Lp, W) && slab_fast_ok(gg, P.lddo, hd, Lp, W) && slab_fast_ok(og, P.ldo, hd, Lp, W);
+    constexpr int NV = 2 * NT;                                // float4 per thread and slab: covers W <= 128
+    const bool fast = ab.bwd_fast && slab_fast_ok<NV>(qg, P.ldq, hd, Lp, W) && slab_fast_ok<NV>(kg, P.ldk, hd, Lp, W) &&
+                      slab_fast_ok<NV>(vg, P.ldv, hd, Lp, W) && slab_fast_ok<NV>(gg, P.lddo, hd, Lp, W) && slab_fast_ok<NV>(og, P.ldo, hd, Lp, W);
     if (fast) {
-        SlabGeom G;
+        SlabGeom<NV> G;
         slab_geom(G, L, hd, Lp, W, ld, tid);
-        SlabRegs rq, rk, rv, rg, ro;                          // one round trip for all five operands (+ the probabilities)
+        SlabRegs<NV> rq, rk, rv, rg, ro;                      // one round trip for all five operands (+ the probabilities)
         slab_issue(rg, G, gg, P.lddo);
         slab_issue(ro, G, og, P.ldo);
         slab_issue(rv, G, vg, P.ldv);
@@ -444,12 +454,13 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_long_fwd_kernel(const float* __
     const size_t tok0 = (size_t)b * S;
     const float* qg = q + (tok0 + q0) * ldq + h * hd;
     const int nq = S - q0 < 64 ? S - q0 : 64;
-    const bool fast = slab_fast_ok(qg, ldq, hd, 64, W) && slab_fast_ok(k + tok0 * ldk + h * hd, ldk, hd, 64, W) &&
-                      slab_fast_ok(v + tok0 * ldv + h * hd, ldv, hd, 64, W);
-    SlabGeom G;
+    constexpr int NV = 8;                                     // 64 rows x W <= 128
+    const bool fast = slab_fast_ok<NV>(qg, ldq, hd, 64, W) && slab_fast_ok<NV>(k + tok0 * ldk + h * hd, ldk, hd, 64, W) &&
+                      slab_fast_ok<NV>(v + tok0 * ldv + h * hd, ldv, hd, 64, W);
+    SlabGeom<NV> G;
     if (fast) {
         slab_geom(G, nq, hd, 64, W, ld, tid);
-        SlabRegs rq;
+        SlabRegs<NV> rq;
         slab_issue(rq, G, qg, ldq);
         slab_commit(rq, G, Qs);
     } else {
@@ -470,9 +481,9 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_long_fwd_kernel(const float* __
         const float* vg = v + (tok0 + kb) * ldv + h * hd;
         const unsigned char kp = key_pad ? key_pad[tok0 + kb + (lane < nk ? lane : 0)] : (unsigned char)0;
         if (fast) {
-            SlabGeom Gk;
+            SlabGeom<NV> Gk;
             slab_geom(Gk, nk, hd, 64, W, ld, tid);
-            SlabRegs rk, rv;
+            SlabRegs<NV> rk, rv;
             slab_issue(rk, Gk, kg, ldk);
             slab_issue(rv, Gk, vg, ldv);
             slab_commit(rk, Gk, Ks);
@@ -582,7 +593,8 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
         const int W = (p.hd + 15) & ~15;
         if (W > maxW) maxW = W;
     }
-    ab.bwd_fast = BWD && Lp * (maxW >> 2) <= NTHR * 4;     // every problem's slabs fit the 4-vector register form
+    // one-round-trip backward: every problem's slabs fit the register form (NV = 2 * Lp/16 float4) and the fifth (O) slab fits LDS
+    ab.bwd_fast = BWD && maxW <= 128 && ((size_t)5 * Lp * (maxW + 2) + Lp) * sizeof(float) <= 160 * 1024;
     const size_t lds = (size_t)(BWD ? (ab.bwd_fast ? 5 : 4) : 3) * Lp * (maxW + 2) * sizeof(float) + (BWD ? Lp * sizeof(float) : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define M2F_ATTN_CASE(N)                                                                                   \

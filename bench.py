@@ -47,13 +47,20 @@ WORKLOADS = {
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def synthetic_batch(cfg, B, L, rank, device):
-    """text = 0.63*randn, audio = 0.23*randn, labels randint(0,7), all dialogues full length."""
+def synthetic_batch(cfg, B, L, rank, device, ragged=False):
+    """text = 0.63*randn, audio = 0.23*randn, labels randint(0,7); headline = all dialogues full length,
+    secondary (`ragged`) = MELD-like lengths clamp(round(N(9.6, 5)), 1, L), pads zeroed, labels -1 on pads."""
     g = torch.Generator().manual_seed(1234 + rank)
     text = torch.randn(B, L, cfg["TEXT"]["embedding_size"], generator=g) * 0.63
     audio = torch.randn(B, L, cfg["AUDIO"]["embedding_size"], generator=g) * 0.23
     emotion = torch.randint(0, 7, (B, L), generator=g)
     mask = torch.zeros(B, L, dtype=torch.bool)
+    if ragged:
+        lengths = torch.clamp(torch.round(torch.randn(B, generator=g) * 5.0 + 9.6), 1, L).to(torch.int64)
+        mask = torch.arange(L)[None, :] >= lengths[:, None]
+        text[mask] = 0.0
+        audio[mask] = 0.0
+        emotion[mask] = -1
     return text.to(device), audio.to(device), mask.to(device), emotion.to(device)
 
 
@@ -109,6 +116,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("M2F_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=os.environ.get("M2F_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ragged", action="store_true", help="secondary workload of SURVEY 8-d: MELD-like dialogue lengths, "
+                    "`value` then counts VALID utterances only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--buckets", type=int, default=8)
@@ -132,7 +141,8 @@ def main():
     opt = FusedAdam(model, lr=5e-5, weight_decay=0.01)
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     stepper = dp.DataParallelStep(model, opt, n_buckets=args.buckets, exchange=exchange)
-    text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device)
+    text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device, ragged=args.ragged)
+    n_valid = int((~mask).sum().item())                # utterances of this rank's batch (= B*L unless --ragged)
     eng = model.engine()
     plan = eng.plan(B, L, True, True)
     use_graph = not args.no_graph
@@ -197,7 +207,12 @@ def main():
     c = model.m2f_config
     _, fb_per_slot = layout.flops_per_slot(c, L)
     ms_per_step = elapsed / args.steps * 1e3
-    utt_per_s = world * B * L / (elapsed / args.steps)
+    nv = torch.tensor([float(n_valid)], dtype=torch.float64, device=device)
+    if world > 1:                                      # SUM over ranks of the valid-utterance counts
+        torch.distributed.all_reduce(nv)
+    n_valid_all = int(nv.item())
+    utt_per_s = n_valid_all / (elapsed / args.steps)
+    slots_per_s = world * B * L / (elapsed / args.steps)          # padded slots are computed too
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
     # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process, so the figure comes from the
@@ -218,16 +233,17 @@ def main():
             "value": utt_per_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl["name"], "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B,
+            "config": {"workload": wl["name"] + (" [MELD-like ragged lengths, valid utterances counted]" if args.ragged else ""),
+                       "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B, "valid_utterances": n_valid_all,
                        "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
                        "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({stepper.reducer.exchange})" if world > 1 else "") + " + fused Adam",
                        "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                        "launches_per_step": plan.num_launches()},
             "loss": loss,
-            "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": B * L / fb_sec, "steps": n_fb,
+            "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": n_valid / fb_sec, "steps": n_fb,
                              "note": "fwd + CE + bwd graph replays on rank 0, optimizer and gradient exchange excluded"},
-            "step_tflops": utt_per_s * fb_per_slot / 1e12,
-            "step_frac_of_peak": utt_per_s * fb_per_slot / 1e12 / (peak * world),
+            "step_tflops": slots_per_s * fb_per_slot / 1e12,
+            "step_frac_of_peak": slots_per_s * fb_per_slot / 1e12 / (peak * world),
             "roofline": {
                 "bound": "mfma", "kernel": "m2f_gemm_kernel (grouped MFMA GEMM: forward / dgrad / wgrad forms)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,

@@ -4,7 +4,6 @@ import os
 import sys
 
 import torch
-from sklearn.metrics import accuracy_score, f1_score
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 for _p in (_HERE, os.path.dirname(_HERE)):
@@ -12,6 +11,7 @@ for _p in (_HERE, os.path.dirname(_HERE)):
         sys.path.insert(0, _p)
 
 from dataset import Dataset, collate_fn  # noqa: E402
+from metrics import BatchScores, move_batch  # noqa: E402
 from model import M2FNet  # noqa: E402
 from utils import get_config  # noqa: E402
 
@@ -22,38 +22,39 @@ except ImportError:
         return it
 
 
+def load_model_weights(model, checkpoint_path, device):
+    """Checkpoint format of the training loop: {'epoch', 'model_state_dict', 'optimizer_state_dict'}."""
+    checkpoint_path = os.path.abspath(checkpoint_path)
+    if not os.path.exists(checkpoint_path):
+        raise ValueError("Checkpoint not found")
+    state = torch.load(checkpoint_path, map_location=device)
+    model.load_state_dict(state["model_state_dict"])
+    return state.get("epoch")
+
+
+def test(model, dl_test, device):
+    """-> (accuracy, weighted_f1) over the loader, per-batch scores averaged unweighted."""
+    scores = BatchScores()
+    model.eval()
+    with torch.inference_mode():
+        for batch in tqdm(dl_test, total=len(dl_test)):
+            text, audio, emotion, padding_mask = move_batch(batch, device)
+            scores.update(model(text, audio, padding_mask), emotion)
+    return scores.result()
+
+
 def main(config=None):
     config = get_config()
     device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
     print(f"Using device {device}...")
-    data_test = Dataset(mode="test")
-    dl_test = torch.utils.data.DataLoader(data_test, collate_fn=collate_fn, **config.test.data_loader)
-    rt = config.get("runtime", {}) or {}
-    model = M2FNet(config.model, precision=rt.get("precision", "fp32")).to(device)
-    path = os.path.abspath(config.checkpoint.load_path)
-    if not os.path.exists(path):
-        raise ValueError("Checkpoint not found")
-    model.load_state_dict(torch.load(path, map_location=device)["model_state_dict"])
+    loader = torch.utils.data.DataLoader(Dataset(mode="test"), collate_fn=collate_fn, **config.test.data_loader)
+    runtime_cfg = config.get("runtime", {}) or {}
+    model = M2FNet(config.model, precision=runtime_cfg.get("precision", "fp32")).to(device)
+    load_model_weights(model, config.checkpoint.load_path, device)
     print("Testing...")
-    accuracy, weighted_f1 = test(model, dl_test, device)
+    accuracy, weighted_f1 = test(model, loader, device)
     print(f"Accuracy=[{accuracy * 100:.3f}%] Weighted_F1=[{weighted_f1 * 100:.3f}%]")
     print("Testing complete")
-
-
-def test(model, dl_test, device):
-    accuracy = weighted_f1 = 0.0
-    model.eval()
-    with torch.inference_mode():
-        for data in tqdm(dl_test, total=len(dl_test)):
-            text, audio = data["text"].to(device), data["audio"].to(device)
-            emotion, padding_mask = data["emotion"].to(device), data["padding_mask"].to(device)
-            outputs = model(text, audio, padding_mask)
-            keep = emotion != -1
-            pred = torch.argmax(outputs, dim=2)[keep].flatten().cpu().numpy()
-            true = emotion[keep].flatten().cpu().numpy()
-            accuracy += accuracy_score(true, pred)
-            weighted_f1 += f1_score(true, pred, average="weighted")
-    return accuracy / len(dl_test), weighted_f1 / len(dl_test)
 
 
 if __name__ == "__main__":

@@ -8,7 +8,6 @@ import sys
 from datetime import datetime
 
 import torch
-from sklearn.metrics import accuracy_score, f1_score
 from sklearn.utils import class_weight
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -17,6 +16,7 @@ for _p in (_HERE, os.path.dirname(_HERE)):
         sys.path.insert(0, _p)
 
 from dataset import Dataset, collate_fn  # noqa: E402
+from metrics import BatchScores, move_batch  # noqa: E402
 from model import M2FNet  # noqa: E402
 from utils import get_config  # noqa: E402
 from mer_amd.optim import FusedAdam, M2FCrossEntropyLoss  # noqa: E402
@@ -31,10 +31,59 @@ try:
 except ImportError:
     wandb = None
 
+CHECKPOINT_KEYS = ("epoch", "model_state_dict", "optimizer_state_dict")
+N_CLASSES = 7
+
 
 def _runtime(cfg, key, default):
-    rt = cfg.get("runtime", {}) if isinstance(cfg, dict) else getattr(cfg, "runtime", {})
-    return rt.get(key, default) if rt else default
+    """Value of the additive ``runtime:`` block of config.yaml (absent in the reference's file -> default)."""
+    block = cfg.get("runtime", {}) if isinstance(cfg, dict) else getattr(cfg, "runtime", {})
+    return block.get(key, default) if block else default
+
+
+# ---- construction of the solver pieces from config.solver -----------------------------------------------------------
+def build_criterion(solver, train_set, device):
+    """CE(ignore_index=-1, label_smoothing=0.1), optionally with sklearn's balanced class weights of the train labels."""
+    if solver.loss_fn != "CE":
+        raise ValueError("Criterion not supported")
+    class_weights = None
+    if solver.balance_classes:
+        balanced = class_weight.compute_class_weight(class_weight="balanced", classes=list(range(N_CLASSES)),
+                                                     y=train_set.get_labels())
+        class_weights = torch.as_tensor(balanced, dtype=torch.float, device=device)
+    return M2FCrossEntropyLoss(weight=class_weights, ignore_index=-1, label_smoothing=0.1)
+
+
+def build_scheduler(solver, optimizer):
+    if not solver.scheduler.enabled:
+        return None
+    if solver.scheduler.scheduler_fn != "ExponentialLR":
+        raise ValueError("Scheduler not supported")
+    return torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=solver.scheduler.gamma)
+
+
+def start_wandb(config):
+    if wandb is None:
+        raise RuntimeError("wandb.enabled is set but the wandb package is not installed")
+    run_name = datetime.now().isoformat().split(".")[0]
+    wandb.init(project=config.wandb.project_name, name=run_name, config=dict(config), entity=config.wandb.entity,
+               settings=wandb.Settings(start_method="spawn" if os.name == "nt" else "fork"),
+               resume="must" if config.wandb.resume_run else False, id=config.wandb.resume_run_id)
+
+
+def resume_if_requested(config, model, optimizer, device):
+    """-> first epoch to run (0, or the checkpoint's epoch + 1)."""
+    path = os.path.abspath(config.checkpoint.load_path)
+    if not (config.checkpoint.load_checkpoint and os.path.exists(path)):
+        return 0
+    state = torch.load(path, map_location=device)
+    model.load_state_dict(state["model_state_dict"])
+    optimizer.load_state_dict(state["optimizer_state_dict"])
+    return state["epoch"] + 1
+
+
+def write_checkpoint(path, epoch, model, optimizer):
+    torch.save(dict(zip(CHECKPOINT_KEYS, (epoch, model.state_dict(), optimizer.state_dict()))), path)
 
 
 def main(config=None):
@@ -43,160 +92,130 @@ def main(config=None):
     print(f"Using device {device}...")
     torch.manual_seed(int(_runtime(config, "seed", 0)))
 
-    data_train = Dataset(mode="train")
-    dl_train = torch.utils.data.DataLoader(data_train, collate_fn=collate_fn, **config.train.data_loader)
-    data_val = Dataset(mode="val")
-    dl_val = torch.utils.data.DataLoader(data_val, collate_fn=collate_fn, **config.val.data_loader)
+    train_set, val_set = Dataset(mode="train"), Dataset(mode="val")
+    dl_train = torch.utils.data.DataLoader(train_set, collate_fn=collate_fn, **config.train.data_loader)
+    dl_val = torch.utils.data.DataLoader(val_set, collate_fn=collate_fn, **config.val.data_loader)
 
     model = M2FNet(config.model, precision=_runtime(config, "precision", "fp32")).to(device)
-
-    if config.solver.loss_fn != "CE":
-        raise ValueError("Criterion not supported")
-    weights = None
-    if config.solver.balance_classes:
-        w = class_weight.compute_class_weight(class_weight="balanced", classes=[0, 1, 2, 3, 4, 5, 6],
-                                              y=data_train.get_labels())
-        weights = torch.as_tensor(w, dtype=torch.float, device=device)
-    criterion = M2FCrossEntropyLoss(weight=weights, ignore_index=-1, label_smoothing=0.1)
-
+    criterion = build_criterion(config.solver, train_set, device)
     optimizer = FusedAdam(model, lr=config.solver.lr, weight_decay=config.solver.weight_decay)
-
     if config.wandb.enabled:
-        if wandb is None:
-            raise RuntimeError("wandb.enabled is set but the wandb package is not installed")
-        wandb.init(project=config.wandb.project_name, name=datetime.now().isoformat().split(".")[0], config=dict(config),
-                   settings=wandb.Settings(start_method="spawn" if os.name == "nt" else "fork"),
-                   entity=config.wandb.entity, resume="must" if config.wandb.resume_run else False,
-                   id=config.wandb.resume_run_id)
-
-    lr_scheduler = None
-    if config.solver.scheduler.enabled:
-        if config.solver.scheduler.scheduler_fn != "ExponentialLR":
-            raise ValueError("Scheduler not supported")
-        lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=config.solver.scheduler.gamma)
-
-    start_epoch = 0
-    load_path = os.path.abspath(config.checkpoint.load_path)
-    if config.checkpoint.load_checkpoint and os.path.exists(load_path):
-        checkpoint = torch.load(load_path, map_location=device)
-        start_epoch = checkpoint["epoch"] + 1
-        model.load_state_dict(checkpoint["model_state_dict"])
-        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        start_wandb(config)
+    lr_scheduler = build_scheduler(config.solver, optimizer)
+    first_epoch = resume_if_requested(config, model, optimizer, device)
 
     print("Training...")
-    training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, start_epoch, config, device)
+    training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, first_epoch, config, device)
     print("Training complete")
 
 
-def _save(path, epoch, model, optimizer):
-    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
-                "optimizer_state_dict": optimizer.state_dict()}, path)
+# ---- early stopping on the validation LOSS with the reference's best-weights file protocol --------------------------
+class EarlyStopper:
+    def __init__(self, settings, save_path):
+        self.enabled = bool(settings.enabled)
+        self.patience = settings.patience
+        self.restore = bool(settings.restore_best_weights)
+        self.save_path = save_path
+        self.best_path = os.path.join(os.path.dirname(save_path), "best_weights.pth")
+        self.best_loss = float("inf")
+        self.epochs_without_improvement = 0
+
+    def should_stop(self, val_loss, epoch, model, optimizer) -> bool:
+        if not self.enabled:
+            return False
+        if val_loss < self.best_loss:
+            self.best_loss, self.epochs_without_improvement = val_loss, 0
+            if self.restore:
+                write_checkpoint(self.best_path, epoch, model, optimizer)
+            return False
+        self.epochs_without_improvement += 1
+        if self.epochs_without_improvement < self.patience:
+            return False
+        print(f"Early stopping: patience {self.patience} reached")
+        if self.restore:                                 # the final checkpoint becomes the best one; the side file goes away
+            best = torch.load(self.best_path)
+            torch.save({k: best[k] for k in CHECKPOINT_KEYS}, self.save_path)
+            os.remove(self.best_path)
+            print(f"Best model at epoch {best['epoch']} restored")
+        return True
 
 
 def training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, start_epoch, config, device):
     solver = config.solver
-    wandb_log = config.wandb.enabled
+    log_to_wandb = config.wandb.enabled
     save_path = os.path.abspath(config.checkpoint.save_path)
     os.makedirs(os.path.dirname(save_path), exist_ok=True)
-    if wandb_log and config.wandb.watch_model:
+    if log_to_wandb and config.wandb.watch_model:
         wandb.watch(model, criterion=criterion, log="all", log_freq=100, log_graph=False)
 
-    stopping = solver.early_stopping.enabled
-    best_path = os.path.join(os.path.dirname(save_path), "best_weights.pth")
-    best_val, bad_epochs = float("inf"), 0
-    train_losses, val_losses = [], []
-
+    stopper = EarlyStopper(solver.early_stopping, save_path)
+    history = {"loss_values": [], "val_loss_values": []}
     for epoch in range(start_epoch, solver.epochs):
-        loss_train = train(model, dl_train, criterion, optimizer, epoch, wandb_log, device)
-        train_losses.append(loss_train)
-        loss_val, accuracy, weighted_f1 = validate(model, dl_val, criterion, device)
-        val_losses.append(loss_val)
+        train_loss = train(model, dl_train, criterion, optimizer, epoch, log_to_wandb, device)
+        val_loss, accuracy, weighted_f1 = validate(model, dl_val, criterion, device)
+        history["loss_values"].append(train_loss)
+        history["val_loss_values"].append(val_loss)
 
         if config.checkpoint.save_checkpoint:
-            _save(save_path, epoch, model, optimizer)
-        lr = optimizer.param_groups[0]["lr"]
-        if solver.scheduler.enabled:
+            write_checkpoint(save_path, epoch, model, optimizer)
+        lr_now = optimizer.param_groups[0]["lr"]
+        if lr_scheduler is not None and solver.scheduler.enabled:
             lr_scheduler.step()
-        print(f"Epoch: {epoch} lr: {lr:.3E} Train=[{loss_train:.3E}] Val=[{loss_val:.3E}] "
+        print(f"Epoch: {epoch} lr: {lr_now:.3E} Train=[{train_loss:.3E}] Val=[{val_loss:.3E}] "
               f"Accuracy=[{accuracy * 100:.3f}%] Weighted_F1=[{weighted_f1 * 100:.3f}%]")
-        if wandb_log:
-            wandb.log({"Params/Epoch": epoch, "Params/Learning_Rate": lr, "Train/Loss": loss_train,
-                       "Validation/Loss": loss_val, "Validation/Accuracy": accuracy,
-                       "Validation/Weighted_F1": weighted_f1})
-
-        if stopping:                                     # on validation LOSS, like the reference
-            if loss_val < best_val:
-                best_val, bad_epochs = loss_val, 0
-                if solver.early_stopping.restore_best_weights:
-                    _save(best_path, epoch, model, optimizer)
-            else:
-                bad_epochs += 1
-                if bad_epochs >= solver.early_stopping.patience:
-                    print(f"Early stopping: patience {solver.early_stopping.patience} reached")
-                    if solver.early_stopping.restore_best_weights:
-                        best = torch.load(best_path)
-                        torch.save({k: best[k] for k in ("epoch", "model_state_dict", "optimizer_state_dict")}, save_path)
-                        os.remove(best_path)
-                        print(f"Best model at epoch {best['epoch']} restored")
-                    break
-    if wandb_log:
+        if log_to_wandb:
+            wandb.log({"Params/Epoch": epoch, "Params/Learning_Rate": lr_now, "Train/Loss": train_loss,
+                       "Validation/Loss": val_loss, "Validation/Accuracy": accuracy, "Validation/Weighted_F1": weighted_f1})
+        if stopper.should_stop(val_loss, epoch, model, optimizer):
+            break
+    if log_to_wandb:
         wandb.finish()
-    return {"loss_values": train_losses}
+    return history
 
 
-def _fusable(model, criterion):
-    cfg = get_config() if os.path.exists("./src/config.yaml") else {}
-    return (bool(_runtime(cfg, "fused_step", True)) and isinstance(criterion, M2FCrossEntropyLoss)
-            and hasattr(model, "train_step"))
+def _step_mode(model, criterion):
+    """(fused, use_graph): the whole loop body as one m2f_step launch when the model / criterion are the HIP-backed ones."""
+    have_cfg = os.path.exists("./src/config.yaml")
+    cfg = get_config() if have_cfg else {}
+    fused = (bool(_runtime(cfg, "fused_step", True)) and isinstance(criterion, M2FCrossEntropyLoss)
+             and hasattr(model, "train_step"))
+    return fused, (bool(_runtime(cfg, "use_graph", True)) if have_cfg else True)
 
 
 def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
-    loss_sum = 0.0
+    """One epoch; returns the mean of the per-batch losses (reference src/train.py:217-243)."""
     model.train()
-    fused = _fusable(model, criterion)
-    use_graph = bool(_runtime(get_config(), "use_graph", True)) if fused and os.path.exists("./src/config.yaml") else True
-    for idx_batch, batch in tqdm(enumerate(dl_train), total=len(dl_train), desc=f"Epoch {epoch}"):
-        text = batch["text"].to(device, non_blocking=True)
-        audio = batch["audio"].to(device, non_blocking=True)
-        emotion = batch["emotion"].to(device, non_blocking=True)
-        padding_mask = batch["padding_mask"].to(device, non_blocking=True)
-
+    fused, use_graph = _step_mode(model, criterion)
+    running = 0.0
+    progress = tqdm(enumerate(dl_train), total=len(dl_train), desc=f"Epoch {epoch}")
+    for step, batch in progress:
+        text, audio, emotion, padding_mask = move_batch(batch, device, non_blocking=True)
         optimizer.zero_grad()
         if fused:
             loss = model.train_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
                                     class_weights=criterion.weight, use_graph=use_graph)
         else:
-            outputs = model(text, audio, padding_mask)
-            loss = criterion(outputs.permute(0, 2, 1), emotion)
+            loss = criterion(model(text, audio, padding_mask).permute(0, 2, 1), emotion)
             loss.backward()
         optimizer.step()
-        loss_sum += loss.item()
-
+        running += loss.item()
         if wandb_log:
-            wandb.log({"Train/Running_loss": loss_sum / (idx_batch + 1),
-                       "Params/Global_step": epoch * len(dl_train) + idx_batch})
-    return loss_sum / len(dl_train)
+            wandb.log({"Train/Running_loss": running / (step + 1), "Params/Global_step": epoch * len(dl_train) + step})
+    return running / len(dl_train)
 
 
 def validate(model, dl_val, criterion, device):
-    loss_sum = accuracy = weighted_f1 = 0.0
+    """-> (mean batch loss, accuracy, weighted_f1); scores by the per-batch rule of ``metrics.BatchScores``."""
     model.eval()
+    scores, loss_total = BatchScores(), 0.0
     with torch.inference_mode():
         for batch in tqdm(dl_val, total=len(dl_val), desc="Validation"):
-            text = batch["text"].to(device)
-            audio = batch["audio"].to(device)
-            emotion = batch["emotion"].to(device)
-            padding_mask = batch["padding_mask"].to(device)
-            outputs = model(text, audio, padding_mask)
-            loss_sum += criterion(outputs.permute(0, 2, 1), emotion).item()
-            # per-batch scores, then an UNWEIGHTED mean over batches (reference src/train.py:261-272)
-            keep = emotion != -1
-            pred = torch.argmax(outputs, dim=2)[keep].flatten().cpu().numpy()
-            true = emotion[keep].flatten().cpu().numpy()
-            accuracy += accuracy_score(true, pred)
-            weighted_f1 += f1_score(true, pred, average="weighted")
-    n = len(dl_val)
-    return loss_sum / n, accuracy / n, weighted_f1 / n
+            text, audio, emotion, padding_mask = move_batch(batch, device)
+            logits = model(text, audio, padding_mask)
+            loss_total += criterion(logits.permute(0, 2, 1), emotion).item()
+            scores.update(logits, emotion)
+    accuracy, weighted_f1 = scores.result()
+    return loss_total / len(dl_val), accuracy, weighted_f1
 
 
 if __name__ == "__main__":

@@ -82,7 +82,7 @@ def test_training_loop_checkpoint_validate_and_test(tmp_path, monkeypatch):
     # non-fused loop body (model(), criterion, backward, step) trains too
     model2 = tr.M2FNet(cfg.model).to(device)
     opt2 = tr.FusedAdam(model2, lr=2e-3, weight_decay=0.01)
-    monkeypatch.setattr(tr, "_fusable", lambda m, c: False)
+    monkeypatch.setattr(tr, "_step_mode", lambda m, c: (False, True))
     l0 = tr.train(model2, dl_train, crit, opt2, 0, False, device)
     l1 = tr.train(model2, dl_train, crit, opt2, 1, False, device)
     assert l1 < l0

@@ -24,6 +24,27 @@ def _shipped_cfg():
         return yaml.safe_load(f)["model"]
 
 
+def test_config_yaml_keeps_every_reference_key_and_default(golden_dir):
+    """src/config.yaml surface: same key names, types and defaults as the reference's file; the only
+    additions live under `runtime:`."""
+    import json
+    with open(os.path.join(golden_dir, "reference_config_keys.json")) as f:
+        ref = json.load(f)
+
+    def flatten(d, prefix=""):
+        out = {}
+        for k, v in d.items():
+            out.update(flatten(v, prefix + k + ".") if isinstance(v, dict) else {prefix + k: v})
+        return out
+    with open(os.path.join(ROOT, "src", "config.yaml")) as f:
+        mine = flatten(yaml.safe_load(f))
+    for k, v in ref.items():
+        assert k in mine, k
+        assert type(mine[k]) is type(v) and mine[k] == v, (k, mine[k], v)
+    extra = sorted(k for k in mine if k not in ref)
+    assert all(k.startswith("runtime.") for k in extra), extra
+
+
 def test_library_exports_every_declared_symbol():
     header = open(runtime.HEADER_PATH).read()
     declared = set(re.findall(r"\b(m2f_[a-z_0-9]+)\s*\(", header))

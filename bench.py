@@ -120,7 +120,9 @@ def main():
                     "`value` then counts VALID utterances only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--buckets", type=int, default=8)
+    ap.add_argument("--buckets", type=int, default=4,
+                    help="gradient all-reduce buckets at N > 1 (31 MB each for the bf16 exchange at C2: large enough for "
+                         "ring bandwidth, small enough that only the last bucket's Adam launch is exposed)")
     ap.add_argument("--grad-exchange", default="auto", choices=["auto", "fp32", "bf16"],
                     help="dtype of the gradient all-reduce at N > 1 (auto: bf16 for --dtype bf16, fp32 for --dtype fp32)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch timing table (kind, us, GFLOP) to this file")

@@ -247,7 +247,7 @@ def main():
             "step_tflops": slots_per_s * fb_per_slot / 1e12,
             "step_frac_of_peak": slots_per_s * fb_per_slot / 1e12 / (peak * world),
             "roofline": {
-                "bound": "mfma", "kernel": "m2f_gemm_kernel (grouped MFMA GEMM: forward / dgrad / wgrad forms)",
+                "bound": "mfma", "kernel": "m2f_gemm16_dense_kernel / m2f_gemm16_table_kernel (bf16) or m2f_gemm_kernel (fp32): grouped MFMA GEMM, forward / dgrad / wgrad launches of one step",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "traffic_source": traffic_src,
                 "launches_per_step": len(gemm_idx), "avg_launch_us": gemm_ms / max(len(gemm_idx), 1) * 1e3,

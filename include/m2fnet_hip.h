@@ -144,6 +144,13 @@ int m2f_embed_layernorm(int T, int d, const int64_t* input_ids, const int64_t* p
 int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            const uint8_t* key_pad, float* out, int ldo, m2f_stream_t stream);
 
+/* fp8 GEMM of the in-loop text encoder (BASELINE C5 asks for fp8 MFMA): C[M,N] = act(acc_scale * A8 B8^T + bias) + res with
+ * A8 [M,K], B8 [N,K] row-major OCP e4m3 bytes (K, lda, ldb multiples of 16; 16-byte aligned), fp32 accumulate on
+ * v_mfma_f32_32x32x16_fp8_fp8; acc_scale = 1 / (scale_a * scale_b) undoes the per-tensor quantisation scales.
+ * activation: 0 none, 1 ReLU, 2 GELU.  Forward only. */
+int m2f_gemm_fp8(int M, int N, int K, const uint8_t* a8, int lda, const uint8_t* b8, int ldb, float acc_scale, float* c, int ldc,
+                 const float* bias, const float* res, int ldres, int activation, m2f_stream_t stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the plan launches) ---------- */
 /* C[M,N] = epilogue(A x B); layout 0: C = A[M,K] B[N,K]^T (nn.Linear forward), 1: C = A[M,K] B[K,N]
  * (input gradient), 2: C = A[K,M]^T B[K,N] (weight gradient; bias_grad[M] = column sums of A).

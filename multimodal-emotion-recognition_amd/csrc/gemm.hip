@@ -214,7 +214,7 @@ struct Stage {
 // Side loads are unconditional (clamped) and issued before the arithmetic; stores are predicated.
 // GELU is a COMPILE-TIME variant: carrying the erf expansion (and its constants) in every instantiation doubled the SGPR
 // spills of the chain kernels (24 -> 52) and cost the M2FNet step 3.4 %; only the text encoder's GEMMs use it.
-template <int MI, int NI, int BM, int BN, bool GELU = false>
+template <int MI, int NI, int BM, int BN, bool GELU = false, bool SCALE = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmProblem& P, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn) {
     const int M = P.M, N = P.N;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[i][j][r] + bv;
+                float x = (SCALE ? acc[i][j][r] * P.acc_scale : acc[i][j][r]) + bv;
                 if (relu_out) x = fmaxf(x, 0.f);
                 v[r] = x;
             }
@@ -721,9 +721,13 @@ __device__ unsigned long long m2f_dbg[64];
 #else
 #define M2F_TS(slot) do {} while (0)
 #endif
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool TABLE, bool GELU = false>
+// FP8: the operands are OCP e4m3 bytes.  The producers are unchanged - a k-tile is BK byte PAIRS per row either way (the
+// launcher passes k and ldq in byte pairs) - only the consumers differ: 2*BK/16 slices of v_mfma_f32_32x32x16_fp8_fp8 with
+// 8-byte fragments, and the epilogue de-quantises the accumulator.
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool TABLE, bool GELU = false, bool FP8 = false>
 __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     static_assert(!(A_RC && !B_RC), "layouts: NT, NN, TN");
+    static_assert(!FP8 || (!A_RC && !B_RC), "fp8: forward form only");
     constexpr bool TN = A_RC && B_RC;
     static_assert(!TN || BM == BN, "the TN stager shares one patch shape for both operands");
     using SAK = Stage16KC<BM, BK>;
@@ -880,6 +884,33 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
         const char* bimg = ldsB + buf * LDS_B;
         const char* ab = aimg + (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;      // row-major images
         const char* bb = bimg + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+        if constexpr (FP8) {
+            // row = 2*BK e4m3 values; slice ks covers 16 of them: lane (row, half) holds bytes [16*ks + 8*half, +8)
+            constexpr int KS8 = BK / 8;
+            const char* a8 = aimg + (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 8;
+            const char* b8 = bimg + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 8;
+#pragma unroll
+            for (int g0 = 0; g0 < KS8; g0 += 4) {
+                long fa[4][MI], fb[4][NI];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[kk][i] = *reinterpret_cast<const long*>(a8 + i * 32 * ROWB + (g0 + kk) * 16);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) fb[kk][j] = *reinterpret_cast<const long*>(b8 + j * 32 * ROWB + (g0 + kk) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         // all fragments of the k-tile first (one exposed LDS latency per tile instead of one per 16-wide k-slice), then
         // the MFMA run back to back
         constexpr int KS = BK / 16;
@@ -930,7 +961,7 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
         }
     }
     M2F_TS(3);
-    gemm_epilogue<MI, NI, BM, BN, GELU>(gb, P, acc, m0, n0, lane, wm, wn);
+    gemm_epilogue<MI, NI, BM, BN, GELU, FP8>(gb, P, acc, m0, n0, lane, wm, wn);
     M2F_TS(4);
   }
 }
@@ -938,9 +969,9 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
 // Two register budgets of the same body.  "wide": up to 256 VGPRs, one workgroup (8 waves) per CU - the launches with
 // at most one tile per CU, where a deep load ring is what matters.  "dense": at most 128 VGPRs (4 waves per SIMD), two
 // workgroups per CU with a shallower ring each - the launches with more tiles than CUs.
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool GELU = false>
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool GELU = false, bool FP8 = false>
 __global__ __launch_bounds__(512) void m2f_gemm16_kernel(const GemmBatch gb) {
-    gemm16_body<A_RC, B_RC, BM, BN, BK, D, false, GELU>(gb);
+    gemm16_body<A_RC, B_RC, BM, BN, BK, D, false, GELU, FP8>(gb);
 }
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void m2f_gemm16_dense_kernel(const GemmBatch gb) {
@@ -956,7 +987,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     gemm16_body<A_RC, B_RC, BM, BN, BK, D, true>(gb);
 }
 
-template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false, bool GELU = false>
+template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false, bool GELU = false, bool FP8 = false>
 hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
     constexpr int lds = 2 * (A_RC ? Stage16RC<BM, BK>::LDS_BYTES : Stage16KC<BM, BK>::LDS_BYTES) +
                         2 * (B_RC ? Stage16RC<BN, BK>::LDS_BYTES : Stage16KC<BN, BK>::LDS_BYTES) + (BK / 8) * BM * 4;
@@ -977,7 +1008,7 @@ hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream
     void (*kern)(const GemmBatch);
     static_assert(!(DENSE && GELU), "the GELU epilogue exists for the wide forward-form kernels only");
     if constexpr (DENSE) kern = m2f_gemm16_dense_kernel<A_RC, B_RC, BM, BN, BK, D>;
-    else kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D, GELU>;
+    else kern = m2f_gemm16_kernel<A_RC, B_RC, BM, BN, BK, D, GELU, FP8>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1204,6 +1235,28 @@ hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);
     return hipErrorInvalidValue;
+}
+
+hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream) {
+    if (gb.count != 1) return hipErrorInvalidValue;
+    GemmProblem& p = gb.pr[0];
+    if (p.M <= 0 || p.N <= 0 || p.a.k[0] <= 0 || p.a.k[1] != 0 || p.a.k[0] != p.b.k[0] || (p.a.k[0] & 15) || !p.a.q[0] || !p.b.q[0] ||
+        (p.a.ldq[0] & 15) || (p.b.ldq[0] & 15) || (reinterpret_cast<uintptr_t>(p.a.q[0]) & 15) || (reinterpret_cast<uintptr_t>(p.b.q[0]) & 15) ||
+        p.gate || (p.flags & (GF_ACCUM | GF_RELU_A | GF_RELU_B)) || p.drop_site)
+        return hipErrorInvalidValue;
+    // the staging code moves 16-byte chunks of a row whatever they hold: hand it the rows in byte pairs
+    p.a.k[0] >>= 1; p.b.k[0] >>= 1; p.a.ldq[0] >>= 1; p.b.ldq[0] >>= 1;
+    const bool gelu = p.flags & GF_GELU_OUT;
+    int tile_m = 256, tile_n = 128;
+    if (m2f_cdiv(p.M, 256) * m2f_cdiv(p.N, 128) < 1024) { tile_m = 128; tile_n = 128; }
+    p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0; p.tile_begin = 0;
+    p.tiles_n = m2f_cdiv(p.N, tile_n);
+    const int t = m2f_cdiv(p.M, tile_m) * p.tiles_n;
+    if (tile_m == 256)
+        return gelu ? launch_cfg16<false, false, 256, 128, 64, 2, false, true, true>(gb, t, stream)
+                    : launch_cfg16<false, false, 256, 128, 64, 2, false, false, true>(gb, t, stream);
+    return gelu ? launch_cfg16<false, false, 128, 128, 64, 3, false, true, true>(gb, t, stream)
+                : launch_cfg16<false, false, 128, 128, 64, 3, false, false, true>(gb, t, stream);
 }
 
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream) {

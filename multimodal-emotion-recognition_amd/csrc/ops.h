@@ -21,6 +21,8 @@ enum {
     GF_RELU_A = 1, GF_RELU_B = 2, GF_RELU_OUT = 4, GF_ACCUM = 8,
     GF_VEC_A = 16, GF_VEC_B = 32,    // set by the launcher when 16-byte loads are legal
     GF_GELU_OUT = 64                 // exact (erf) GELU instead of ReLU in the epilogue (RoBERTa's intermediate.dense)
+    // (fp8 launches, m2f_launch_gemm_fp8: a.q / b.q point at e4m3 bytes, k / ldq count BYTE PAIRS, the accumulator is
+    //  multiplied by acc_scale = 1 / (scale_a * scale_b) before the epilogue terms)
 };
 
 struct GemmOperand {
@@ -55,6 +57,7 @@ struct GemmProblem {
     float* bias_grad;         // wgrad only: [M] column sums of A over the reduction dim, or null
     int M, N, ldc, ldres, ldgate;
     float gate_scale;
+    float acc_scale;          // fp8 launches only: de-quantisation factor applied to the accumulator
     uint32_t drop_site;       // 0 = no dropout in the epilogue
     uint32_t flags;
     int tile_begin, tiles_n;  // filled by the launcher
@@ -100,6 +103,9 @@ hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStr
 // TABLE form, bf16 mode, k-contiguous (NT) operands staged from gb.table[i].{a,b}.q.  Host-side preparation of a table:
 // m2f_gemm_table_layout fills tile_begin / tiles_n of every problem for `tile` and returns the tile -> problem map.
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream);
+// fp8 (OCP e4m3) operands, forward form only, single problem: C = act(acc_scale * A8 B8^T + bias) + res.  K % 16 == 0,
+// lda / ldb % 16 == 0, 16-byte aligned operands.  (SURVEY 8-f4 / BASELINE C5: the text encoder's GEMMs.)
+hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream);
 #ifdef __cplusplus
 #include <vector>
 int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob);

@@ -74,6 +74,19 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: int = NT, precision: int = ru
     return (c, bg) if bias_grad else c
 
 
+def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, acc_scale: float, bias: Optional[torch.Tensor] = None,
+             res: Optional[torch.Tensor] = None, activation: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a8 [M, K], b8 [N, K] torch.float8_e4m3fn -> fp32 [M, N] = act(acc_scale * a8 b8^T + bias) + res."""
+    runtime.require_gpu()
+    assert a8.dtype == torch.float8_e4m3fn and b8.dtype == torch.float8_e4m3fn
+    M, K = a8.shape
+    N = b8.shape[0]
+    c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a8.device)
+    check(lib().m2f_gemm_fp8(M, N, K, ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), float(acc_scale), ptr(c), _ld(c), ptr(bias),
+                             ptr(res), _ld(res) if res is not None else 0, int(activation), stream_ptr()), "m2f_gemm_fp8")
+    return c
+
+
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_pad: torch.Tensor, B: int, L: int, H: int,
                   drop_site: int = 0, drop_p: float = 0.0, rng: Optional[torch.Tensor] = None):
     """q/k/v: [B*L, H*hd] (possibly column slices).  Returns (out [B*L, H*hd], probs^T [B*H, Lp, Lp])."""

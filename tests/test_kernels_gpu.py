@@ -110,6 +110,22 @@ def test_gemm_large_m_tile_and_gelu_epilogue():
     _close(got32, 0.5 * pre32 * (1.0 + torch.erf(pre32 / 2.0 ** 0.5)), 1e-5, "fp32 GEMM + GELU")
 
 
+@pytest.mark.parametrize("shape", [(300, 200, 64), (1024, 768, 768), (4096 * 9 + 5, 1024 + 40, 256)])
+def test_gemm_fp8_matches_dequantised_reference(shape):
+    """fp8 (OCP e4m3) operands, fp32 accumulate: exact against an fp32 product of the SAME quantised values (the MFMA
+    multiplies e4m3 x e4m3 exactly and accumulates in fp32), with the de-quantisation scale, bias, GELU and residual."""
+    M, N, K = shape
+    a, b = _rand(M, K, seed=41), _rand(N, K, seed=42) * 0.05
+    bias, res = _rand(N, seed=43), _rand(M, N, seed=44)
+    sa, sb = 16.0, 448.0 / b.abs().max().item()
+    a8, b8 = (a * sa).to(torch.float8_e4m3fn), (b * sb).to(torch.float8_e4m3fn)
+    pre = (a8.float() @ b8.float().t()) / (sa * sb) + bias
+    got = F.gemm_fp8(a8, b8, 1.0 / (sa * sb), bias=bias, res=res, activation=2)
+    ref = 0.5 * pre * (1.0 + torch.erf(pre / 2.0 ** 0.5)) + res
+    _close(got, ref, 1e-4, "fp8 GEMM + GELU + residual")            # fp32 accumulation order only
+    _close(F.gemm_fp8(a8, b8, 1.0 / (sa * sb)), (a8.float() @ b8.float().t()) / (sa * sb), 1e-4, "fp8 GEMM plain")
+
+
 @pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
 def test_gemm_epilogue_and_segments(prec):
     M, N, K0, K1 = 96, 80, 64, 40

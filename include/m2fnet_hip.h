@@ -147,9 +147,14 @@ int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq,
 /* fp8 GEMM of the in-loop text encoder (BASELINE C5 asks for fp8 MFMA): C[M,N] = act(acc_scale * A8 B8^T + bias) + res with
  * A8 [M,K], B8 [N,K] row-major OCP e4m3 bytes (K, lda, ldb multiples of 16; 16-byte aligned), fp32 accumulate on
  * v_mfma_f32_32x32x16_fp8_fp8; acc_scale = 1 / (scale_a * scale_b) undoes the per-tensor quantisation scales.
- * activation: 0 none, 1 ReLU, 2 GELU.  Forward only. */
+ * activation: 0 none, 1 ReLU, 2 GELU.  c8 (nullable): the result is written as e4m3(result * c8_scale) at c8[m*ldc + n]
+ * INSTEAD of fp32 c (an activation whose only reader is the next fp8 GEMM, e.g. the FFN hidden layer).  Forward only. */
 int m2f_gemm_fp8(int M, int N, int K, const uint8_t* a8, int lda, const uint8_t* b8, int ldb, float acc_scale, float* c, int ldc,
-                 const float* bias, const float* res, int ldres, int activation, m2f_stream_t stream);
+                 const float* bias, const float* res, int ldres, int activation, uint8_t* c8, float c8_scale,
+                 m2f_stream_t stream);
+
+/* dst[i] = e4m3(clamp(src[i] * scale, +-448)), n % 4 == 0: operand quantisation for m2f_gemm_fp8. */
+int m2f_quantize_fp8(const float* src, uint8_t* dst, int64_t n, float scale, m2f_stream_t stream);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels the plan launches) ---------- */
 /* C[M,N] = epilogue(A x B); layout 0: C = A[M,K] B[N,K]^T (nn.Linear forward), 1: C = A[M,K] B[K,N]

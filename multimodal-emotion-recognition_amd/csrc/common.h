@@ -51,3 +51,13 @@ __device__ __forceinline__ uint16_t m2f_bf16_bits(float x) {
     return __builtin_bit_cast(uint16_t, h);
 }
 __device__ __forceinline__ float m2f_bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+// fp32 -> OCP e4m3 byte, saturating at +-448 (the value range the fp8 GEMM operands use)
+__device__ __forceinline__ uint32_t m2f_fp8x4_bits(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);     // bytes 0, 1
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);      // bytes 2, 3
+    return (uint32_t)w;
+}

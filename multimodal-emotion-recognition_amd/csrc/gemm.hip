@@ -327,6 +327,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
                 if (gate) x = gv[r] > 0.f ? x * gscale : 0.f;
                 v[r] = x + cv[r];
             }
+            if constexpr (SCALE) {
+                if (P.c8) {                                     // block-uniform: e4m3 result instead of fp32 C
+                    const float s8 = P.c8_scale;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) P.c8[oc[r]] = (uint8_t)(m2f_fp8x4_bits(v[r] * s8, 0.f, 0.f, 0.f) & 0xFFu);
+                    continue;
+                }
+            }
             if (interior) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(C + (size_t)(oc[r] * 4u)) = v[r];

@@ -58,6 +58,8 @@ struct GemmProblem {
     int M, N, ldc, ldres, ldgate;
     float gate_scale;
     float acc_scale;          // fp8 launches only: de-quantisation factor applied to the accumulator
+    uint8_t* c8;              // fp8 launches only (nullable): the result goes out as e4m3(v * c8_scale) at c8[m*ldc + n]
+    float c8_scale;           //   INSTEAD of fp32 C (an activation whose only reader is the next fp8 GEMM)
     uint32_t drop_site;       // 0 = no dropout in the epilogue
     uint32_t flags;
     int tile_begin, tiles_n;  // filled by the launcher
@@ -236,6 +238,9 @@ hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream);
 hipError_t m2f_launch_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                                const float* gamma, const float* beta, float eps, float* out, int ld, int T, int d, ShadowMap sh,
                                hipStream_t stream);
+
+// dst[i] = e4m3(clamp(src[i] * scale, +-448)) for n values (n % 4 == 0): operand quantisation of the fp8 GEMMs
+hipError_t m2f_launch_quant_fp8(const float* src, uint8_t* dst, int64_t n, float scale, hipStream_t stream);
 
 // in-place: x[t, c] *= keep(site, t*d + c) / (1 - p)
 hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,

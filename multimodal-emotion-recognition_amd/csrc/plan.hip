@@ -1289,8 +1289,14 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
     return 0;
 }
 
+int m2f_quantize_fp8(const float* src, uint8_t* dst, int64_t n, float scale, m2f_stream_t stream) {
+    M2F_HIP(m2f_launch_quant_fp8(src, dst, n, scale, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int m2f_gemm_fp8(int M, int N, int K, const uint8_t* a8, int lda, const uint8_t* b8, int ldb, float acc_scale, float* c, int ldc,
-                 const float* bias, const float* res, int ldres, int activation, m2f_stream_t stream) {
+                 const float* bias, const float* res, int ldres, int activation, uint8_t* c8, float c8_scale,
+                 m2f_stream_t stream) {
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     GemmProblem p;
@@ -1298,7 +1304,8 @@ int m2f_gemm_fp8(int M, int N, int K, const uint8_t* a8, int lda, const uint8_t*
     p.a.q[0] = reinterpret_cast<const uint16_t*>(a8); p.a.ldq[0] = lda; p.a.k[0] = K;
     p.b.q[0] = reinterpret_cast<const uint16_t*>(b8); p.b.ldq[0] = ldb; p.b.k[0] = K;
     p.M = M; p.N = N; p.c = c; p.ldc = ldc; p.bias = bias; p.res = res; p.ldres = ldres;
-    p.gate_scale = 1.f; p.acc_scale = acc_scale;
+    p.gate_scale = 1.f; p.acc_scale = acc_scale; p.c8 = c8; p.c8_scale = c8_scale;
+    if (!c && !c8) return fail("m2f_gemm_fp8: no output buffer");
     p.flags = (activation == 1 ? GF_RELU_OUT : 0) | (activation == 2 ? GF_GELU_OUT : 0);
     gb.pr[0] = p; gb.count = 1; gb.sh = g_sh;
     M2F_HIP(m2f_launch_gemm_fp8(gb, static_cast<hipStream_t>(stream)));

@@ -718,6 +718,22 @@ hipError_t m2f_launch_embed_ln(const int64_t* ids, const int64_t* pos_ids, const
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void m2f_quant_fp8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, int64_t n4, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(src)[i];
+        reinterpret_cast<uint32_t*>(dst)[i] = m2f_fp8x4_bits(x[0] * scale, x[1] * scale, x[2] * scale, x[3] * scale);
+    }
+}
+
+hipError_t m2f_launch_quant_fp8(const float* src, uint8_t* dst, int64_t n, float scale, hipStream_t stream) {
+    if (n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 3)) return hipErrorInvalidValue;
+    const int64_t n4 = n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(m2f_quant_fp8_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n4, scale);
+    return hipGetLastError();
+}
+
 hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream) {
     if (a.T < 1 || !a.rows) return hipErrorInvalidValue;
     hipLaunchKernelGGL(m2f_gather_kernel, dim3(m2f_cdiv(a.T, 4)), dim3(256), 0, stream, a);

@@ -75,16 +75,33 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: int = NT, precision: int = ru
 
 
 def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, acc_scale: float, bias: Optional[torch.Tensor] = None,
-             res: Optional[torch.Tensor] = None, activation: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """a8 [M, K], b8 [N, K] torch.float8_e4m3fn -> fp32 [M, N] = act(acc_scale * a8 b8^T + bias) + res."""
+             res: Optional[torch.Tensor] = None, activation: int = 0, out: Optional[torch.Tensor] = None,
+             out8: Optional[torch.Tensor] = None, out8_scale: float = 1.0) -> torch.Tensor:
+    """a8 [M, K], b8 [N, K] torch.float8_e4m3fn -> fp32 [M, N] = act(acc_scale * a8 b8^T + bias) + res, or - with `out8` -
+    the same result quantised as e4m3(result * out8_scale) into out8 [M, N] (no fp32 output)."""
     runtime.require_gpu()
     assert a8.dtype == torch.float8_e4m3fn and b8.dtype == torch.float8_e4m3fn
     M, K = a8.shape
     N = b8.shape[0]
+    if out8 is not None:
+        assert out8.dtype == torch.float8_e4m3fn and out8.shape == (M, N)
+        check(lib().m2f_gemm_fp8(M, N, K, ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), float(acc_scale), None, out8.stride(0),
+                                 ptr(bias), ptr(res), _ld(res) if res is not None else 0, int(activation), ptr(out8),
+                                 float(out8_scale), stream_ptr()), "m2f_gemm_fp8")
+        return out8
     c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a8.device)
     check(lib().m2f_gemm_fp8(M, N, K, ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), float(acc_scale), ptr(c), _ld(c), ptr(bias),
-                             ptr(res), _ld(res) if res is not None else 0, int(activation), stream_ptr()), "m2f_gemm_fp8")
+                             ptr(res), _ld(res) if res is not None else 0, int(activation), None, 1.0, stream_ptr()), "m2f_gemm_fp8")
     return c
+
+
+def quantize_fp8(src: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """e4m3(clamp(src * scale, +-448)) of a contiguous fp32 tensor."""
+    runtime.require_gpu()
+    assert src.is_contiguous() and src.dtype == torch.float32
+    dst = out if out is not None else torch.empty(src.shape, dtype=torch.float8_e4m3fn, device=src.device)
+    check(lib().m2f_quantize_fp8(ptr(src), ptr(dst), src.numel(), float(scale), stream_ptr()), "m2f_quantize_fp8")
+    return dst
 
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_pad: torch.Tensor, B: int, L: int, H: int,

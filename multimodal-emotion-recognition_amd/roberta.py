@@ -47,8 +47,12 @@ class RobertaEncoder(torch.nn.Module):
         self.hd = self.d // self.n_head
         if self.hd > 128 or self.d > 2048:
             raise ValueError("head dim <= 128 and hidden size <= 2048")
-        assert precision in ("bf16", "fp32")
-        self.precision = runtime.BF16 if precision == "bf16" else runtime.F32
+        assert precision in ("bf16", "fp32", "fp8")
+        # fp8 (BASELINE C5): the four GEMMs of every layer on fp8 MFMA (OCP e4m3, fp32 accumulate); weights quantised once
+        # with a per-tensor scale 448 / amax, activations with fixed scales (LayerNorm / attention outputs x16, GELU
+        # outputs x8, saturating) - everything else (embeddings, attention, LayerNorm, residual stream) stays fp32
+        self.fp8 = precision == "fp8"
+        self.precision = runtime.F32 if precision == "fp32" else runtime.BF16
         d, Fi = self.d, self.inter
         P = torch.nn.Parameter
         z = torch.zeros
@@ -110,7 +114,11 @@ class RobertaEncoder(torch.nn.Module):
                    "wo2": lyr.output.dense.weight.detach().contiguous(), "bo2": lyr.output.dense.bias.detach(),
                    "g2": lyr.output.LayerNorm.weight.detach(), "b2": lyr.output.LayerNorm.bias.detach()}
             for k in ("wqkv", "wo", "wi", "wo2"):
-                ent[k + "16"] = sh(ent[k])
+                ent[k + "16"] = sh(ent[k]) if not self.fp8 else None
+                if self.fp8:
+                    scale = 448.0 / max(float(ent[k].abs().max()), 1e-12)
+                    ent[k + "8"] = (ent[k] * scale).clamp_(-448.0, 448.0).to(torch.float8_e4m3fn).contiguous()
+                    ent[k + "8s"] = scale
             layers.append(ent)
         self._packed = layers
         self._packed_versions = self._versions()
@@ -131,6 +139,8 @@ class RobertaEncoder(torch.nn.Module):
                 views16[name] = ws16[off: off + n].view(T, cols)
                 off += (n + 63) // 64 * 64
             w = {"ws": ws, "ws16": ws16, "v": views, "v16": views16, "stats": torch.empty(T, 2, dtype=torch.float32, device=dev)}
+            if self.fp8:
+                w["q8"] = {n: torch.empty(T, c, dtype=torch.float8_e4m3fn, device=dev) for n, c in (("x", d), ("ctx", d), ("y1", d), ("h", Fi))}
             self._ws[key] = w
         return w
 
@@ -151,7 +161,7 @@ class RobertaEncoder(torch.nn.Module):
         prec = self.precision
         w = self._workspace(B, S, dev)
         v, v16 = w["v"], w["v16"]
-        bf16 = prec == runtime.BF16
+        bf16 = prec == runtime.BF16 and not self.fp8
         check(lib().m2f_set_shadow_map(ptr(w["ws"]) if bf16 else None, ptr(w["ws16"]) if bf16 else None,
                                        w["ws"].numel() if bf16 else 0), "m2f_set_shadow_map")
         try:
@@ -164,23 +174,30 @@ class RobertaEncoder(torch.nn.Module):
                                             ptr(emb.token_type_embeddings.weight), ptr(emb.LayerNorm.weight), ptr(emb.LayerNorm.bias),
                                             self.eps, ptr(v["x"]), d, stream_ptr()), "m2f_embed_layernorm")
 
-            def s16(*names):
-                return tuple((v16[n] if (bf16 and n is not None and n in v16) else None) for n in names)
+            ACT_SCALE = {"x": 16.0, "ctx": 16.0, "y1": 16.0, "h": 8.0}
+
+            def linear(a_name, wkey, L, out, bias, res=None, act=0, out8=None):
+                if self.fp8:
+                    sa = ACT_SCALE[a_name]
+                    q8 = w["q8"][a_name]
+                    if a_name != "h":                                        # h arrives quantised from the FFN1 epilogue
+                        F.quantize_fp8(v[a_name], sa, out=q8)
+                    F.gemm_fp8(q8, L[wkey + "8"], 1.0 / (sa * L[wkey + "8s"]), bias=bias, res=res, activation=act, out=out,
+                               out8=w["q8"][out8] if out8 else None, out8_scale=ACT_SCALE[out8] if out8 else 1.0)
+                else:
+                    F.gemm(v[a_name], L[wkey], F.NT, prec, bias=bias, res=res, relu_out=act, out=out,
+                           shadows=(v16[a_name], None, L[wkey + "16"], None) if bf16 else None)
             for L in self._packed:
-                F.gemm(v["x"], L["wqkv"], F.NT, prec, bias=L["bqkv"], out=v["qkv"],
-                       shadows=(v16["x"], None, L["wqkv16"], None) if bf16 else None)
+                linear("x", "wqkv", L, v["qkv"], L["bqkv"])
                 qkv = v["qkv"]
                 check(lib().m2f_attention_long_fwd(B, S, H, hd, ptr(qkv), 3 * d, qkv.data_ptr() + 4 * d, 3 * d,
                                                    qkv.data_ptr() + 8 * d, 3 * d, ptr(key_pad), ptr(v["ctx"]), d, stream_ptr()),
                       "m2f_attention_long_fwd")
-                F.gemm(v["ctx"], L["wo"], F.NT, prec, bias=L["bo"], res=v["x"], out=v["t"],
-                       shadows=(v16["ctx"], None, L["wo16"], None) if bf16 else None)
+                linear("ctx", "wo", L, v["t"], L["bo"], res=v["x"])
                 check(lib().m2f_layernorm_fwd(T, d, ptr(v["t"]), ptr(L["g1"]), ptr(L["b1"]), None, ptr(v["y1"]), ptr(w["stats"]),
                                               self.eps, stream_ptr()), "m2f_layernorm_fwd")
-                F.gemm(v["y1"], L["wi"], F.NT, prec, bias=L["bi"], relu_out=2, out=v["h"],
-                       shadows=(v16["y1"], None, L["wi16"], None) if bf16 else None)
-                F.gemm(v["h"], L["wo2"], F.NT, prec, bias=L["bo2"], res=v["y1"], out=v["t"],
-                       shadows=(v16["h"], None, L["wo216"], None) if bf16 else None)
+                linear("y1", "wi", L, v["h"], L["bi"], act=2, out8="h" if self.fp8 else None)
+                linear("h", "wo2", L, v["t"], L["bo2"], res=v["y1"])
                 check(lib().m2f_layernorm_fwd(T, d, ptr(v["t"]), ptr(L["g2"]), ptr(L["b2"]), None, ptr(v["x"]), ptr(w["stats"]),
                                               self.eps, stream_ptr()), "m2f_layernorm_fwd")
             out = v["x"].view(B, S, d).clone()

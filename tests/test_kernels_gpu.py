@@ -123,7 +123,23 @@ def test_gemm_fp8_matches_dequantised_reference(shape):
     got = F.gemm_fp8(a8, b8, 1.0 / (sa * sb), bias=bias, res=res, activation=2)
     ref = 0.5 * pre * (1.0 + torch.erf(pre / 2.0 ** 0.5)) + res
     _close(got, ref, 1e-4, "fp8 GEMM + GELU + residual")            # fp32 accumulation order only
-    _close(F.gemm_fp8(a8, b8, 1.0 / (sa * sb)), (a8.float() @ b8.float().t()) / (sa * sb), 1e-4, "fp8 GEMM plain")
+    plain = (a8.float() @ b8.float().t()) / (sa * sb)
+    _close(F.gemm_fp8(a8, b8, 1.0 / (sa * sb)), plain, 1e-4, "fp8 GEMM plain")
+    # e4m3 output (the FFN hidden layer never exists in fp32): same values as quantising the fp32 result
+    out8 = torch.empty(M, N, dtype=torch.float8_e4m3fn, device=DEV)
+    F.gemm_fp8(a8, b8, 1.0 / (sa * sb), bias=bias, activation=2, out8=out8, out8_scale=8.0)
+    want8 = F.quantize_fp8((0.5 * pre * (1.0 + torch.erf(pre / 2.0 ** 0.5))).contiguous(), 8.0)
+    diff = (out8.float() - want8.float()).abs()
+    assert (diff > 0).float().mean().item() < 2e-3             # a rounding boundary flips only where the fp32 sums differ in the last bits
+    assert (diff <= 0.13 * want8.float().abs() + 2.0 ** -9).all()   # and then by one e4m3 step (2^-9 in the subnormal range)
+
+
+def test_quantize_fp8_matches_torch_and_saturates():
+    x = _rand(1000, 64, seed=51) * 100.0
+    got = F.quantize_fp8(x, 2.0)
+    ref = (x * 2.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    assert torch.equal(got.float(), ref.float())
+    assert got.float().abs().max().item() == 448.0
 
 
 @pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--model", default="large", choices=sorted(GEOM))
     ap.add_argument("--utterances", type=int, default=512)
     ap.add_argument("--seq", type=int, default=64)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--with-fusion-step", action="store_true",
@@ -67,7 +67,7 @@ def main():
     T = a.utterances * a.seq
     gemm = 2.0 * T * (4 * d * d + 2 * d * F) * Lr
     attn = 4.0 * a.seq * a.seq * (d // H) * a.utterances * H * Lr
-    peak = 2500.0 if a.dtype == "bf16" else 157.3
+    peak = {"bf16": 2500.0, "fp32": 157.3, "fp8": 5000.0}[a.dtype]
     print(json.dumps({"metric": ("utterances/sec, text encoder forward + M2FNet training step (BASELINE C5 data flow, RoBERTa-%s geometry)"
                                  if a.with_fusion_step else
                                  "utterances/sec, in-loop text encoder forward (RoBERTa-%s geometry, random weights)") % a.model,

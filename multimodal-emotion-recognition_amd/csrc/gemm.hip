@@ -214,7 +214,33 @@ struct Stage {
 // Side loads are unconditional (clamped) and issued before the arithmetic; stores are predicated.
 // GELU is a COMPILE-TIME variant: carrying the erf expansion (and its constants) in every instantiation doubled the SGPR
 // spills of the chain kernels (24 -> 52) and cost the M2FNet step 3.4 %; only the text encoder's GEMMs use it.
-template <int MI, int NI, int BM, int BN, bool GELU = false, bool SCALE = false>
+// erf for the GELU epilogues.  POLY (bf16 / fp8 kernels): odd degree-13 minimax polynomial on |z| <= 3, max error 4.3e-4
+// (far inside bf16 operand rounding), 7 FMAs, no quarter-rate instructions; otherwise Abramowitz-Stegun 7.1.26 (1.5e-7) on
+// the hardware exp / rcp (libm's erff is several times slower still).
+template <bool POLY>
+__device__ __forceinline__ float m2f_gelu(float x) {
+    const float z = x * 0.70710678118654752f;
+    float e;
+    if constexpr (POLY) {
+        const float zc = fminf(fmaxf(z, -3.0f), 3.0f), t = zc * zc;
+        float p = 3.4737140595098026e-06f;
+        p = p * t - 0.0001298444258281961f;
+        p = p * t + 0.0020486447028815746f;
+        p = p * t - 0.018010087311267853f;
+        p = p * t + 0.098881796002388f;
+        p = p * t - 0.3658691942691803f;
+        p = p * t + 1.1261212825775146f;
+        e = fminf(fmaxf(p * zc, -1.0f), 1.0f);
+    } else {
+        const float az = fabsf(z);
+        const float tt = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+        const float poly = tt * (0.254829592f + tt * (-0.284496736f + tt * (1.421413741f + tt * (-1.453152027f + tt * 1.061405429f))));
+        e = copysignf(1.0f - poly * __expf(-az * az), z);
+    }
+    return 0.5f * x * (1.0f + e);
+}
+
+template <int MI, int NI, int BM, int BN, bool GELU = false, bool SCALE = false, bool GELU_POLY = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmProblem& P, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn) {
     const int M = P.M, N = P.N;
@@ -303,15 +329,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmPro
             if constexpr (GELU) {
                 if (flags & GF_GELU_OUT) {                      // block-uniform
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on the hardware exp / rcp: libm's erff made
-                        // the epilogue of the text encoder's FFN GEMM cost more than half of its k-loop (845 vs 530 us)
-                        const float z = v[r] * 0.70710678118654752f, az = fabsf(z);
-                        const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
-                        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-                        const float e = 1.0f - poly * __expf(-az * az);
-                        v[r] = 0.5f * v[r] * (1.0f + copysignf(e, z));
-                    }
+                    for (int r = 0; r < 16; ++r) v[r] = m2f_gelu<GELU_POLY>(v[r]);
                 }
             }
             if (site) {
@@ -970,7 +988,7 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
         }
     }
     M2F_TS(3);
-    gemm_epilogue<MI, NI, BM, BN, GELU, FP8>(gb, P, acc, m0, n0, lane, wm, wn);
+    gemm_epilogue<MI, NI, BM, BN, GELU, FP8, true>(gb, P, acc, m0, n0, lane, wm, wn);
     M2F_TS(4);
   }
 }

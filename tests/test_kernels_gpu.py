@@ -122,7 +122,7 @@ def test_gemm_fp8_matches_dequantised_reference(shape):
     pre = (a8.float() @ b8.float().t()) / (sa * sb) + bias
     got = F.gemm_fp8(a8, b8, 1.0 / (sa * sb), bias=bias, res=res, activation=2)
     ref = 0.5 * pre * (1.0 + torch.erf(pre / 2.0 ** 0.5)) + res
-    _close(got, ref, 1e-4, "fp8 GEMM + GELU + residual")            # fp32 accumulation order only
+    _close(got, ref, 1e-3, "fp8 GEMM + GELU + residual")            # accumulation order + the 4.3e-4 polynomial erf
     plain = (a8.float() @ b8.float().t()) / (sa * sb)
     _close(F.gemm_fp8(a8, b8, 1.0 / (sa * sb)), plain, 1e-4, "fp8 GEMM plain")
     # e4m3 output (the FFN hidden layer never exists in fp32): same values as quantising the fp32 result
@@ -130,8 +130,10 @@ def test_gemm_fp8_matches_dequantised_reference(shape):
     F.gemm_fp8(a8, b8, 1.0 / (sa * sb), bias=bias, activation=2, out8=out8, out8_scale=8.0)
     want8 = F.quantize_fp8((0.5 * pre * (1.0 + torch.erf(pre / 2.0 ** 0.5))).contiguous(), 8.0)
     diff = (out8.float() - want8.float()).abs()
-    assert (diff > 0).float().mean().item() < 2e-3             # a rounding boundary flips only where the fp32 sums differ in the last bits
-    assert (diff <= 0.13 * want8.float().abs() + 2.0 ** -9).all()   # and then by one e4m3 step (2^-9 in the subnormal range)
+    assert (diff > 0).float().mean().item() < 0.10             # the kernel's erf is a 4.3e-4 polynomial: a few % of the values land on the other side of an e4m3 rounding boundary
+    # ... and then by one e4m3 step (2^-9 in the subnormal range) plus the polynomial's absolute error (<= 0.5 |x| 4.3e-4,
+    # times the output scale 8): e.g. GELU of x < -4 is exactly 0 in the kernel and -1e-4 in the reference
+    assert (diff <= 0.13 * want8.float().abs() + 2.0 ** -9 + 0.015).all()
 
 
 def test_quantize_fp8_matches_torch_and_saturates():

@@ -45,7 +45,7 @@ def main():
         assert a.utterances % L == 0
         nb = a.utterances // L
         mcfg = B.model_cfg(768, cfg["hidden_size"], 768, 8, 8, 8, 6, 5)            # C3 geometry with d_text = encoder width
-        model = M2FNet(mcfg, precision=a.dtype).cuda().train()
+        model = M2FNet(mcfg, precision="bf16" if a.dtype == "fp8" else a.dtype).cuda().train()     # fp8 exists for the encoder only
         opt = FusedAdam(model, lr=5e-5, weight_decay=0.01)
         _, audio, mask, emotion = B.synthetic_batch(mcfg, nb, L, 0, torch.device("cuda"))
         fusion = {"dialogues": nb, "max_utt": L}

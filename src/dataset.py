@@ -70,3 +70,28 @@ def collate_fn(batch):
         text[i, :n], audio[i, :n] = d["text"], d["audio"]
         emotion[i, :n] = torch.cat([torch.as_tensor(e).reshape(1) for e in d["emotion"]]).to(torch.int64)
     return {"text": text, "audio": audio, "padding_mask": emotion == -1, "emotion": emotion}
+
+
+class DeviceLoader:
+    """Drop-in for ``torch.utils.data.DataLoader(Dataset, collate_fn=collate_fn, batch_size, shuffle)`` with both embedding
+    tables resident in HBM (``runtime.device_batcher: True``): one gather kernel per batch fills the same
+    {"text", "audio", "padding_mask", "emotion"} dict, on the device, with dialogues in DataLoader order (a fresh
+    ``torch.randperm`` per epoch when shuffling, the last batch partial - torch's ``drop_last=False`` default)."""
+
+    def __init__(self, dataset, batch_size=32, shuffle=False, device="cuda", seed=None, **_ignored_loader_kwargs):
+        from mer_amd.batcher import DeviceDialogueBatcher
+        self.batch_size, self.shuffle = int(batch_size), bool(shuffle)
+        self.n = len(dataset)
+        self.batcher = DeviceDialogueBatcher(dataset.text_embeddings, dataset.audio_embeddings, dataset._labels, dataset.rows,
+                                             device=device)
+        self.generator = torch.Generator()
+        if seed is not None:
+            self.generator.manual_seed(int(seed))
+
+    def __len__(self):
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = torch.randperm(self.n, generator=self.generator).tolist() if self.shuffle else list(range(self.n))
+        for start in range(0, self.n, self.batch_size):
+            yield self.batcher.gather(order[start: start + self.batch_size])

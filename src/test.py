@@ -10,7 +10,7 @@ for _p in (_HERE, os.path.dirname(_HERE)):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-from dataset import Dataset, collate_fn  # noqa: E402
+from dataset import Dataset, DeviceLoader, collate_fn  # noqa: E402
 from metrics import BatchScores, move_batch  # noqa: E402
 from model import M2FNet  # noqa: E402
 from utils import get_config  # noqa: E402
@@ -47,8 +47,11 @@ def main(config=None):
     config = get_config()
     device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
     print(f"Using device {device}...")
-    loader = torch.utils.data.DataLoader(Dataset(mode="test"), collate_fn=collate_fn, **config.test.data_loader)
     runtime_cfg = config.get("runtime", {}) or {}
+    if runtime_cfg.get("device_batcher", False):
+        loader = DeviceLoader(Dataset(mode="test"), device=device, **config.test.data_loader)
+    else:
+        loader = torch.utils.data.DataLoader(Dataset(mode="test"), collate_fn=collate_fn, **config.test.data_loader)
     model = M2FNet(config.model, precision=runtime_cfg.get("precision", "fp32")).to(device)
     load_model_weights(model, config.checkpoint.load_path, device)
     print("Testing...")

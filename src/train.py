@@ -15,7 +15,7 @@ for _p in (_HERE, os.path.dirname(_HERE)):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-from dataset import Dataset, collate_fn  # noqa: E402
+from dataset import Dataset, DeviceLoader, collate_fn  # noqa: E402
 from metrics import BatchScores, move_batch  # noqa: E402
 from model import M2FNet  # noqa: E402
 from utils import get_config  # noqa: E402
@@ -93,8 +93,12 @@ def main(config=None):
     torch.manual_seed(int(_runtime(config, "seed", 0)))
 
     train_set, val_set = Dataset(mode="train"), Dataset(mode="val")
-    dl_train = torch.utils.data.DataLoader(train_set, collate_fn=collate_fn, **config.train.data_loader)
-    dl_val = torch.utils.data.DataLoader(val_set, collate_fn=collate_fn, **config.val.data_loader)
+    if _runtime(config, "device_batcher", False):          # embedding tables in HBM, one gather kernel per batch
+        dl_train = DeviceLoader(train_set, device=device, seed=_runtime(config, "seed", 0), **config.train.data_loader)
+        dl_val = DeviceLoader(val_set, device=device, **config.val.data_loader)
+    else:
+        dl_train = torch.utils.data.DataLoader(train_set, collate_fn=collate_fn, **config.train.data_loader)
+        dl_val = torch.utils.data.DataLoader(val_set, collate_fn=collate_fn, **config.val.data_loader)
 
     model = M2FNet(config.model, precision=_runtime(config, "precision", "fp32")).to(device)
     criterion = build_criterion(config.solver, train_set, device)

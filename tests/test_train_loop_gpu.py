@@ -88,6 +88,26 @@ def test_training_loop_checkpoint_validate_and_test(tmp_path, monkeypatch):
     assert l1 < l0
 
 
+def test_device_loader_yields_the_dataloader_batches():
+    """runtime.device_batcher: the HBM-resident loader produces exactly the batches of DataLoader + collate_fn (same
+    dialogue order without shuffling, same tensors, last batch partial) and a permutation of them when shuffling."""
+    import dataset as ds
+    d = _dataset(21, 16, 8, 7)
+    ref = list(torch.utils.data.DataLoader(d, collate_fn=ds.collate_fn, batch_size=8, shuffle=False))
+    dev = ds.DeviceLoader(d, batch_size=8, shuffle=False, device="cuda", num_workers=2, pin_memory=True)
+    got = list(dev)
+    assert len(dev) == len(ref) == len(got) == 3
+    for a, b in zip(got, ref):
+        for k in ("text", "audio", "padding_mask", "emotion"):
+            assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k]), k
+    sh = ds.DeviceLoader(d, batch_size=8, shuffle=True, device="cuda", seed=3)
+    e1 = torch.cat([b["emotion"][~b["padding_mask"]] for b in sh]).cpu()
+    e2 = torch.cat([b["emotion"][~b["padding_mask"]] for b in sh]).cpu()
+    all_lab = torch.cat([b["emotion"][~b["padding_mask"]] for b in ref])
+    assert sorted(e1.tolist()) == sorted(all_lab.tolist()) == sorted(e2.tolist())      # every utterance once per epoch
+    assert e1.tolist() != e2.tolist()                                                  # new permutation each epoch
+
+
 def test_collate_fn_contract_matches_oracle():
     import dataset as ds
     d = _dataset(6, 16, 8, 5)

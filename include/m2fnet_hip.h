@@ -105,6 +105,13 @@ int m2f_gather_dialogues(const float* text_table, int d_text, const float* audio
 int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream,
                    int max_entries, int* kinds, float* ms, double* flops);
 
+/* Calibration of m2f_step_timed's intervals: the mean device time between the two hipEventRecords of a pair with
+ * NOTHING between them (*empty_pair_ms) and with a one-thread kernel between them (*trivial_kernel_pair_ms; needs
+ * scratch_rng_state = 4 device uint32, may be NULL to skip), over `pairs` pairs on `stream`.  rocprofv3 reports the
+ * kernel's own begin..end; an event interval adds this record/dispatch overhead to it.  Synchronises the stream. */
+int m2f_event_overhead(uint32_t* scratch_rng_state, int pairs, float* empty_pair_ms, float* trivial_kernel_pair_ms,
+                       m2f_stream_t stream);
+
 /* Advances the dropout RNG state by one step on the device (what nn.Dropout's generator advance is to the
  * reference; m2f_step does it itself). */
 int m2f_rng_advance(uint32_t* rng_state, m2f_stream_t stream);

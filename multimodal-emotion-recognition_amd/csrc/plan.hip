@@ -1218,6 +1218,35 @@ int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights,
     return n;
 }
 
+int m2f_event_overhead(uint32_t* scratch_rng_state, int pairs, float* empty_pair_ms, float* trivial_kernel_pair_ms,
+                       m2f_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pairs < 1 || pairs > 4096) return fail("m2f_event_overhead: pairs must be in [1, 4096]");
+    std::vector<hipEvent_t> ev(4 * (size_t)pairs);
+    for (auto& e : ev) M2F_HIP(hipEventCreate(&e));
+    for (int i = 0; i < pairs; ++i) {                       // the interval of m2f_step_timed with nothing inside
+        (void)hipEventRecord(ev[2 * i], s);
+        (void)hipEventRecord(ev[2 * i + 1], s);
+    }
+    for (int i = 0; i < pairs; ++i) {                       // ... and with a one-thread kernel inside
+        (void)hipEventRecord(ev[2 * (pairs + i)], s);
+        if (scratch_rng_state) (void)m2f_launch_rng_advance(scratch_rng_state, s);
+        (void)hipEventRecord(ev[2 * (pairs + i) + 1], s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    double acc[2] = {0, 0};
+    for (int i = 0; i < 2 * pairs; ++i) {
+        float t = 0.f;
+        if (e == hipSuccess) (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+        acc[i / pairs] += t;
+    }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    if (e != hipSuccess) { hipfail(e, "hipStreamSynchronize"); return -1; }
+    if (empty_pair_ms) *empty_pair_ms = (float)(acc[0] / pairs);
+    if (trivial_kernel_pair_ms) *trivial_kernel_pair_ms = (float)(acc[1] / pairs);
+    return 0;
+}
+
 int m2f_gather_dialogues(const float* text_table, int d_text, const float* audio_table, int d_audio,
                          const int64_t* label_table, const int32_t* rows, int T, float* text_out, int ld_text,
                          float* audio_out, int ld_audio, uint8_t* key_pad_out, int64_t* labels_out, m2f_stream_t stream) {

@@ -67,6 +67,7 @@ SIGNATURES = {
     "m2f_step": (c_int, [c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "m2f_step_timed": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_int),
                                ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double)]),
+    "m2f_event_overhead": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "m2f_gather_dialogues": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                      c_int, c_void_p, c_void_p, c_void_p]),
     "m2f_rng_advance": (c_int, [c_void_p, c_void_p]),
@@ -270,6 +271,14 @@ class Plan:
         if h and _lib is not None:
             _lib.m2f_plan_destroy(h)
             self.handle = None
+
+
+def event_overhead(pairs: int = 200):
+    """-> (empty hipEvent pair, pair around a one-thread kernel) in ms: what a step_timed interval holds besides the kernel."""
+    scratch = torch.zeros(4, dtype=torch.int32, device="cuda")
+    a, b = c_float(0), c_float(0)
+    check(lib().m2f_event_overhead(scratch.data_ptr(), pairs, ctypes.byref(a), ctypes.byref(b), stream_ptr()), "m2f_event_overhead")
+    return a.value, b.value
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,

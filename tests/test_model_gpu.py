@@ -209,6 +209,23 @@ def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monke
     assert checked >= 20
 
 
+@pytest.mark.parametrize("tile", ["64", "256"])
+def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, tile, monkeypatch):
+    """The persistent weight-gradient table kernel exists as 64x64, 128x128 (default) and 256x128 builds
+    (M2F_TABLE_TILE, read when a plan is built): same operands and k order, so the gradients agree to fp32 summation noise."""
+    fx = _load(golden_dir, "c2_slice")
+    cfg, text, audio, key_pad, emotion = _inputs("c2_slice", fx)
+    batch = (text, audio, key_pad, emotion)
+    g_default = _train_grads(cfg, "bf16", batch)
+    monkeypatch.setenv("M2F_TABLE_TILE", tile)
+    g_variant = _train_grads(cfg, "bf16", batch)
+    monkeypatch.delenv("M2F_TABLE_TILE")
+    for k, ref in g_default.items():
+        scale = ref.abs().max().item()
+        if scale >= 1e-6:
+            assert (g_variant[k] - ref).abs().max().item() <= 1e-4 * scale, k
+
+
 def test_live_oracle_full_size_properties():
     """BASELINE config C2' shape (B=32, L=16, 768/768/768) at reduced depth, checked live against the oracle,
     plus size-independent properties at full size: pad-content independence and dialogue independence."""

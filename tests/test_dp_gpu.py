@@ -32,12 +32,16 @@ def _fresh(cfg, precision):
 
 @pytest.fixture(scope="module")
 def one_rank_group():
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import socket
+    with socket.socket() as sk:                          # a free rendezvous port on this box
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     rank, world, _ = dp.init_distributed()
     assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
     yield
     dist.destroy_process_group()
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         os.environ.pop(k, None)
 
 

@@ -591,12 +591,20 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
 __device__ __forceinline__ float bf16lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 
+// 16-byte load through an explicitly GLOBAL pointer (a native vector type: HIP's uint4 is a class whose copy goes through a
+// generic reference and loses the address space again)
+typedef unsigned int m2f_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16_global(const void* p) {
+    const m2f_u32x4 r = *(const __attribute__((address_space(1))) m2f_u32x4*)p;
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+
 template <int BR, int BK>
 struct Stage16KC {                       // element (row, k) at q[row*ld + k]
     static constexpr int KCH = BK / 8, NT = BR * KCH / 256;
     static constexpr int ROWB = BK * 2 + 16, LDS_BYTES = BR * ROWB;
     static_assert(NT >= 1 && (BR * KCH) % 256 == 0, "tile split");
-    uint4 v[NT];
+    m2f_u32x4 v[NT];
     uint32_t off[NT];                    // BYTE offset of chunk t from the row-panel base at kbase = 0 (row clamped)
     int rows_, row0_, kpad_, kbase_, tid_;
     bool full_;
@@ -611,24 +619,57 @@ struct Stage16KC {                       // element (row, k) at q[row*ld + k]
         }
     }
     // uniform 64-bit base + zero-extended 32-bit lane offset: the saddr form of global_load (no per-load 64-bit VALU add)
-    __device__ __forceinline__ static uint4 ld16(const char* base, uint32_t o) {
-        return *reinterpret_cast<const uint4*>(base + (size_t)o);
+    // The address-space cast matters for the table kernel: its operand pointers are read from device memory, so the compiler
+    // cannot prove them global and emits FLAT loads - which also count on lgkmcnt, share ordering with the ds_writes and
+    // turn every counted wait of the ring into vmcnt(0) lgkmcnt(0).
+    __device__ __forceinline__ static m2f_u32x4 ld16(const char* base, uint32_t o) {
+        return *(const __attribute__((address_space(1))) m2f_u32x4*)(base + (size_t)o);
     }
+    template <bool ASM = false>
     __device__ __forceinline__ void issue(const uint16_t* __restrict__ q, int kseg, int kbase) {
         kpad_ = (kseg + 7) & ~7; kbase_ = kbase;
         full_ = (row0_ + BR <= rows_) && (kbase + BK <= kpad_);
         const char* pt = reinterpret_cast<const char*>(q + kbase);
-        if (full_) {
+        // ONE straight-line path for interior and edge tiles (selects, no branch): with the loads of a set split over two
+        // branches the waitcnt pass loses count at the merge and every wait of the ring becomes vmcnt(0)
+        static_assert(256 % KCH == 0, "chunk column is the same for every t");
+        const int kc = tid_ % KCH;
+        const uint32_t back = (kbase + 8 * kc < kpad_) ? 0u : 16u * kc;     // past the padded width: this tile's first chunk
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = ld16(pt, off[t]);
-        } else {
+        for (int t = 0; t < NT; ++t) {
+            uint32_t o = off[t] - back;
+            o = kseg == 0 ? 0u : o;               // dead tile past the end of the k-loop: every lane reads the same 16 bytes
+            if constexpr (ASM) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[t]) : "v"(o), "s"(pt) : "memory");
+            else v[t] = ld16(pt, o);
+        }
+    }
+    // ASM issue: the compiler does not know these registers are in flight, so the caller waits by hand - `newer` = loads
+    // issued after the last one of this set.  The registers are tied through the statement so that no use can be scheduled
+    // above it.
+    template <int NEWER>
+    __device__ __forceinline__ void wait_loaded() {
+        static_assert(NEWER >= 0 && NEWER <= 63 && NT <= 16, "vmcnt immediate / operand count");
+        if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[0]) : "n"(NEWER) : "memory");
+        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(NEWER) : "memory");
+        else if constexpr (NT == 4)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(NEWER) : "memory");
+        else if constexpr (NT == 8)
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]),
+                         "+v"(v[7]) : "n"(NEWER) : "memory");
+        else static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "chunks per thread");
+    }
+    // Branch-free variant for the table kernel (its operands never carry a ReLU flag): edge chunks are zeroed with selects,
+    // so the registers of a set are only touched in straight-line code and the ring keeps counted vmcnt waits.
+    __device__ __forceinline__ void store_select(char* lds) {
+        const int kc = tid_ % KCH;
+        const bool kok = full_ || (kbase_ + 8 * kc < kpad_);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int kc = (tid_ + 256 * t) % KCH;
-                uint32_t o = (kbase + 8 * kc < kpad_) ? off[t] : off[t] - 16u * kc;      // else: this tile's first chunk
-                if (kseg == 0) o = 0u;            // dead tile past the end of the k-loop: every lane reads the same 16 bytes
-                v[t] = ld16(pt, o);
-            }
+        for (int t = 0; t < NT; ++t) {
+            const int r = (tid_ + 256 * t) / KCH;
+            const bool ok = kok && (full_ || row0_ + r < rows_);
+            m2f_u32x4 x = v[t];
+            x.x = ok ? x.x : 0u; x.y = ok ? x.y : 0u; x.z = ok ? x.z : 0u; x.w = ok ? x.w : 0u;
+            *reinterpret_cast<m2f_u32x4*>(lds + r * ROWB + kc * 16) = x;
         }
     }
     __device__ __forceinline__ void store(char* lds, bool relu) {
@@ -638,9 +679,9 @@ struct Stage16KC {                       // element (row, k) at q[row*ld + k]
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int id = tid_ + 256 * t, r = id / KCH, kc = id % KCH;
-                uint4 x = v[t];
+                m2f_u32x4 x = v[t];
                 const bool ok = full_ || ((row0_ + r < rows_) && (kbase_ + 8 * kc < kpad_));
-                if (!ok) x = make_uint4(0u, 0u, 0u, 0u);
+                if (!ok) x = (m2f_u32x4){0u, 0u, 0u, 0u};
                 if (relu) { x.x = relu_bf16x2(x.x); x.y = relu_bf16x2(x.y); x.z = relu_bf16x2(x.z); x.w = relu_bf16x2(x.w); }
                 v[t] = x;
             }
@@ -648,7 +689,7 @@ struct Stage16KC {                       // element (row, k) at q[row*ld + k]
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int id = tid_ + 256 * t, r = id / KCH, kc = id % KCH;
-            *reinterpret_cast<uint4*>(lds + r * ROWB + kc * 16) = v[t];
+            *reinterpret_cast<m2f_u32x4*>(lds + r * ROWB + kc * 16) = v[t];
         }
     }
 };
@@ -686,7 +727,7 @@ struct Stage16RC {   // element (row, k) at q[k*ld + row]; one 8(k) x 8(row) pat
             int o = off + j * ld_;
             if (!full_) o = (kbase + 8 * kp_ + j < kseg) ? o : off - 8 * kp_ * ld_ - kbase * ld_;   // else: k = 0 row
             if (kseg == 0) o = 0;                 // dead tile past the end of the k-loop: one broadcast line
-            v[j] = *reinterpret_cast<const uint4*>(pt + o);
+            v[j] = ld16_global(pt + o);
         }
     }
     __device__ __forceinline__ void store(char* lds, bool relu, bool do_cs, float (&cs)[8]) {
@@ -765,6 +806,10 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     constexpr int LDS_B = B_RC ? SBR::LDS_BYTES : SBK::LDS_BYTES;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int U = (D % 2 == 0) ? D : 2 * D;                 // unroll so that set and LDS-buffer indices are static
+    // NT form: the staging loads are issued from inline asm and waited for with hand-counted vmcnt (Stage16KC::wait_loaded).
+    // hipcc's own waitcnt insertion answers the ring with vmcnt(0) as soon as the control flow around it is not trivial
+    // (always in the table kernel: 3 sets, 6-fold unroll), which drains all sets in flight at every k-tile.
+    constexpr bool ASM_LOADS = !A_RC && !B_RC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const bool producer = threadIdx.x >= 256;                   // wave-uniform
@@ -846,12 +891,28 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
             const int ks = tv ? (seg ? ak1 : ak0) : 0;
             const uint16_t* const qa = seg ? aq1 : aq0;
             const uint16_t* const qb = seg ? bq1 : bq0;
+            if constexpr (ASM_LOADS) {
+                st.ak.template issue<true>(qa, ks, kbase);
+                st.bk.template issue<true>(qb, ks, kbase);
+                return;
+            }
             if constexpr (!A_RC) st.ak.issue(qa, ks, kbase);
             if constexpr (!B_RC) st.bk.issue(qb, ks, kbase);
             if constexpr (!A_RC && B_RC) st.br.issue(qb, ks, kbase);
             if constexpr (TN) st.br.issue(second_half ? qb : qa, ks, kbase);
         };
         auto store = [&](Set& st, int buf) {
+            if constexpr (ASM_LOADS) {
+                // every round issues one set and stores one: D - 1 whole sets are younger than the one stored now
+                constexpr int PER_SET = SAK::NT + SBK::NT;
+                st.ak.template wait_loaded<(D - 1) * PER_SET + SBK::NT>();
+                st.bk.template wait_loaded<(D - 1) * PER_SET>();
+            }
+            if constexpr (TABLE && !A_RC && !B_RC) {
+                st.ak.store_select(ldsA + buf * LDS_A);
+                st.bk.store_select(ldsB + buf * LDS_B);
+                return;
+            }
             if constexpr (!A_RC) st.ak.store(ldsA + buf * LDS_A, reluA);
             if constexpr (!B_RC) st.bk.store(ldsB + buf * LDS_B, reluB);
             if constexpr (!A_RC && B_RC) { float dummy[8]; st.br.store(ldsB + buf * LDS_B, reluB, false, dummy); }
@@ -870,17 +931,20 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
         lds_barrier();                                          // (B0) tile 0 visible
         issue(sets[0], D);
         M2F_TS(4);
-        for (int kt0 = 0; kt0 < nk; kt0 += U) {
+        // The loop is LEFT (not skipped through) when the k-tiles run out: a path that skips the rest of an unrolled round
+        // and still reaches the loop header carries a different number of outstanding loads, and the waitcnt pass then
+        // answers every wait at the header with vmcnt(0) - draining the ring once per round.
+        for (int kt0 = 0;; kt0 += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int kt = kt0 + u;
-                if (kt < nk) {                                   // block-uniform
-                    store(sets[(u + 1) % D], (u + 1) & 1);       // tile kt+1 (all-zero past the end) while tile kt is multiplied
-                    lds_barrier();                               // (B1 per tile)
-                    issue(sets[(u + 1) % D], kt + 1 + D);
-                }
+                if (kt >= nk) goto k_tiles_done;                 // block-uniform
+                store(sets[(u + 1) % D], (u + 1) & 1);           // tile kt+1 (all-zero past the end) while tile kt is multiplied
+                lds_barrier();                                   // (B1 per tile)
+                issue(sets[(u + 1) % D], kt + 1 + D);
             }
         }
+k_tiles_done:
         if constexpr (TN) {
             if (has_bg) {
                 // threads 0..127 hold column sums of their 8 rows over their k-group: red[kp][row], then fixed-order sum
@@ -1237,6 +1301,8 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
     const int tile_m = tile, tile_n = tile == 256 ? 128 : tile;
     tile_prob.clear();
     if (prs.size() > 65535) return -1;
+    for (const GemmProblem& p : prs)
+        if (p.flags & (GF_RELU_A | GF_RELU_B)) return -1;       // the table kernel stages operands as they are (store_select)
     int t = 0;
     for (size_t i = 0; i < prs.size(); ++i) {
         GemmProblem& p = prs[i];

@@ -792,6 +792,39 @@ __device__ unsigned long long m2f_dbg[64];
 // FP8: the operands are OCP e4m3 bytes.  The producers are unchanged - a k-tile is BK byte PAIRS per row either way (the
 // launcher passes k and ldq in byte pairs) - only the consumers differ: 2*BK/16 slices of v_mfma_f32_32x32x16_fp8_fp8 with
 // 8-byte fragments, and the epilogue de-quantises the accumulator.
+// Epilogue of the weight-gradient table kernel (plain stores: no bias / residual / gate / shadow).  The consumers multiply with
+// the operands SWAPPED, so a lane holds C[row = lane & 31][8 * g + 4 * (lane >> 5) + 0..3] of its 32x32 block: four consecutive
+// columns per register quad -> one 16-byte store instead of four 4-byte ones (16 instead of 64 store instructions per wave
+// and 64x64 quadrant).
+template <int MI, int NI, int BM, int BN>
+__device__ __forceinline__ void table_epilogue_t(const GemmProblem& P, f32x16 (&acc)[MI][NI], int m0, int n0, int lane, int wm, int wn) {
+    const int M = P.M, N = P.N, ldc = P.ldc;
+    float* __restrict__ C = P.c;
+    const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (m0 + BM <= M) && (n0 + BN <= N);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+            const int col0 = n0 + wn * (BN / 2) + j * 32 + 4 * (lane >> 5);
+            if (vec) {                                              // block-uniform
+                float* dst = C + (size_t)row * ldc + col0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                }
+            } else if (row < M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = col0 + 8 * (r >> 2) + (r & 3);
+                    if (col < N) C[(size_t)row * ldc + col] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool TABLE, bool GELU = false, bool FP8 = false>
 __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     static_assert(!(A_RC && !B_RC), "layouts: NT, NN, TN");
@@ -810,6 +843,8 @@ __device__ __forceinline__ void gemm16_body(const GemmBatch& gb) {
     // hipcc's own waitcnt insertion answers the ring with vmcnt(0) as soon as the control flow around it is not trivial
     // (always in the table kernel: 3 sets, 6-fold unroll), which drains all sets in flight at every k-tile.
     constexpr bool ASM_LOADS = !A_RC && !B_RC;
+    // table kernel: transposed accumulators + 16-byte stores (table_epilogue_t); its problems carry no epilogue terms
+    constexpr bool TABLE_T = TABLE && !A_RC && !B_RC && !FP8 && !GELU;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const bool producer = threadIdx.x >= 256;                   // wave-uniform
@@ -1026,7 +1061,8 @@ k_tiles_done:
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                    if constexpr (TABLE_T) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks][j], a[ks][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     };
 
     M2F_TS(1);
@@ -1052,7 +1088,8 @@ k_tiles_done:
         }
     }
     M2F_TS(3);
-    gemm_epilogue<MI, NI, BM, BN, GELU, FP8, true>(gb, P, acc, m0, n0, lane, wm, wn);
+    if constexpr (TABLE_T) table_epilogue_t<MI, NI, BM, BN>(P, acc, m0, n0, lane, wm, wn);
+    else gemm_epilogue<MI, NI, BM, BN, GELU, FP8, true>(gb, P, acc, m0, n0, lane, wm, wn);
     M2F_TS(4);
   }
 }
@@ -1273,6 +1310,9 @@ bool vec_ok(const GemmOperand& o, bool rc, int rows) {
     return true;
 }
 
+#ifndef M2F_T256_D
+#define M2F_T256_D 2          // register sets in flight of the 256x128 table build (experiment knob)
+#endif
 template <int BM, int BN, int BK, int D, bool DENSE>
 hipError_t launch_table16(const GemmBatch& gb, hipStream_t stream) {
     constexpr int lds = 2 * Stage16KC<BM, BK>::LDS_BYTES + 2 * Stage16KC<BN, BK>::LDS_BYTES + (BK / 8) * BM * 4;
@@ -1302,7 +1342,9 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
     tile_prob.clear();
     if (prs.size() > 65535) return -1;
     for (const GemmProblem& p : prs)
-        if (p.flags & (GF_RELU_A | GF_RELU_B)) return -1;       // the table kernel stages operands as they are (store_select)
+        if ((p.flags & (GF_RELU_A | GF_RELU_B | GF_RELU_OUT | GF_ACCUM | GF_GELU_OUT)) || p.bias || p.res || p.gate || p.drop_site ||
+            p.c8 || p.a.k[1] || p.b.k[1])
+            return -1;       // the table kernel stages operands as they are (store_select) and stores plain results (table_epilogue_t)
     int t = 0;
     for (size_t i = 0; i < prs.size(); ++i) {
         GemmProblem& p = prs[i];
@@ -1324,7 +1366,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile == 256) return launch_table16<256, 128, 64, 2, false>(gb, stream);
+    if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);
     return hipErrorInvalidValue;

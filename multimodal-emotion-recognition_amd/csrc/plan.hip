@@ -886,11 +886,11 @@ int build_plan(m2f_plan& P, char* ws_base) {
         if (tblock.size() > 65535) table_ok = false;
     }
     int total_tiles = 0;
-    // 128x128 tiles.  M2F_TABLE_TILE=64|256 (read when a plan is built; 256 = 256x128) selects the other builds of the table
-    // kernel: 256x128 moves a quarter fewer bytes through L1 and measures 225 vs 242 us at C2 (register sets 3 deep: 246 us),
-    // 64x64 is slower; the tests run all three against each other
+    // 256x128 tiles (a quarter fewer operand bytes through L1 than 128x128: 145 vs 183 us at C2 once the staging ring kept its
+    // loads in flight).  M2F_TABLE_TILE=64|128 (read when a plan is built) selects the other builds of the table kernel; the
+    // tests run all three against each other
     const char* tt_env = getenv("M2F_TABLE_TILE");
-    const int table_tile = (tt_env && (atoi(tt_env) == 64 || atoi(tt_env) == 256)) ? atoi(tt_env) : 128;
+    const int table_tile = (tt_env && (atoi(tt_env) == 64 || atoi(tt_env) == 128)) ? atoi(tt_env) : 256;
     if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, table_tile, tile_prob);
     if (total_tiles <= 0) table_ok = false;
     GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;

@@ -27,6 +27,15 @@
 #include <cstdlib>
 #include <cstring>
 
+// Experiment knobs (register sets in flight).  NOTE: builds that spill VGPRs are NOT safe with the inline-asm staging
+// loads (see Stage16KC::wait_loaded): D = 3 of the 128-VGPR chain build spills and faults.
+#ifndef M2F_CHAIN_D
+#define M2F_CHAIN_D 2         // register sets in flight of the 64x64 chain build (experiment knob)
+#endif
+#ifndef M2F_T256_D
+#define M2F_T256_D 2          // register sets in flight of the 256x128 table build (experiment knob)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1276,7 +1285,10 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
     // tiles than CUs).  Deeper rings (4, 6) gain nothing - the vector L1 caps the misses in flight, not the software - and
     // cost code size: same-box A/B of the whole step, 2.130 (depth 4 + separate 256-VGPR build) -> 2.107 ms; the step
     // alternates between ~8 kernels, so every kilobyte of code is instruction-cache traffic at each launch.
-    return launch_cfg16<A_RC, B_RC, 64, 64, 128, 2, true>(gb, t, stream);
+#ifdef M2F_CHAIN_WIDE_D        // experiment: launches that give a CU one workgroup at most run a 256-VGPR build with a deeper ring
+    if (t <= 256) return launch_cfg16<A_RC, B_RC, 64, 64, 128, M2F_CHAIN_WIDE_D, false>(gb, t, stream);
+#endif
+    return launch_cfg16<A_RC, B_RC, 64, 64, 128, M2F_CHAIN_D, true>(gb, t, stream);
 }
 
 // can every operand of every problem be staged from its bf16 shadow with 16-byte loads?
@@ -1310,9 +1322,6 @@ bool vec_ok(const GemmOperand& o, bool rc, int rows) {
     return true;
 }
 
-#ifndef M2F_T256_D
-#define M2F_T256_D 2          // register sets in flight of the 256x128 table build (experiment knob)
-#endif
 template <int BM, int BN, int BK, int D, bool DENSE>
 hipError_t launch_table16(const GemmBatch& gb, hipStream_t stream) {
     constexpr int lds = 2 * Stage16KC<BM, BK>::LDS_BYTES + 2 * Stage16KC<BN, BK>::LDS_BYTES + (BK / 8) * BM * 4;

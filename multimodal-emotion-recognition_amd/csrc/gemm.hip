@@ -1282,9 +1282,11 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
     }
     if (tile == 128) return launch_cfg16<A_RC, B_RC, 128, 128, 64, 3>(gb, t, stream);
     // ONE 64x64 build for every launch size: ring depth 2 within 128 VGPRs (two workgroups per CU when the launch has more
-    // tiles than CUs).  Deeper rings (4, 6) gain nothing - the vector L1 caps the misses in flight, not the software - and
-    // cost code size: same-box A/B of the whole step, 2.130 (depth 4 + separate 256-VGPR build) -> 2.107 ms; the step
-    // alternates between ~8 kernels, so every kilobyte of code is instruction-cache traffic at each launch.
+    // tiles than CUs).  Deeper rings gain nothing for these launches (start-up and dispatch bound, not ring bound) and cost
+    // code size: same-box A/B of the whole step 2.130 (depth 4 + separate 256-VGPR build) -> 2.107 ms, and again after the
+    // ring kept its loads in flight: 2.34 / 2.38 (depth 3 / 4, 256-VGPR build for launches of
+    // at most 256 tiles) vs 2.32 ms; the step alternates between ~8 kernels, so every kilobyte of code is instruction-cache
+    // traffic at each launch.
 #ifdef M2F_CHAIN_WIDE_D        // experiment: launches that give a CU one workgroup at most run a 256-VGPR build with a deeper ring
     if (t <= 256) return launch_cfg16<A_RC, B_RC, 64, 64, 128, M2F_CHAIN_WIDE_D, false>(gb, t, stream);
 #endif

@@ -4,6 +4,7 @@ and default initialisation, config validation mirrors the reference, and nothing
 import ctypes
 import os
 import re
+import sys
 import types
 
 import numpy as np
@@ -167,3 +168,28 @@ def test_dialogue_row_index_matches_dataset_semantics():
     assert [r.tolist() for r in rows] == [[1, 0, 3], [4, 6, 2], [5]]
     ids, rows2 = build_dialogue_index(dia, utt)
     assert ids == [5, 2, 9] and [r.tolist() for r in rows2] == [r.tolist() for r in rows]
+
+
+def test_spill_guard_of_the_gemm_build(tmp_path):
+    """csrc/check_spills.py (run by the Makefile on hipcc's resource remarks): a k-contiguous (NT) m2f_gemm16 kernel that
+    spills VGPRs must fail the build - its staging loads are issued from inline asm and a spilled register would be reused
+    while the load is still in flight; spills in the other forms, and remarks without any such kernel, are reported as such."""
+    import subprocess
+    script = os.path.join(ROOT, "multimodal-emotion-recognition_amd", "csrc", "check_spills.py")
+
+    def remarks(entries):
+        out = []
+        for name, spill in entries:
+            out.append(f"gemm.hip:1:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]")
+            out.append("gemm.hip:1:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]")
+            out.append(f"gemm.hip:1:1: remark:     VGPRs Spill: {spill} [-Rpass-analysis=kernel-resource-usage]")
+        p = tmp_path / "r.txt"
+        p.write_text("\n".join(out) + "\n")
+        return subprocess.run([sys.executable, script, str(p)], capture_output=True, text=True)
+
+    nt = "_ZN12_GLOBAL__N_123m2f_gemm16_dense_kernelILb0ELb0ELi64ELi64ELi128ELi2EEEv9GemmBatch"
+    tn = "_ZN12_GLOBAL__N_123m2f_gemm16_dense_kernelILb1ELb1ELi64ELi64ELi128ELi2EEEv9GemmBatch"
+    assert remarks([(nt, 0), (tn, 58)]).returncode == 0
+    bad = remarks([(nt, 204), (tn, 0)])
+    assert bad.returncode == 1 and "spills 204 VGPRs" in bad.stderr
+    assert remarks([(tn, 0)]).returncode != 0          # no kernel of the guarded form found: the remark format changed

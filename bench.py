@@ -7,7 +7,8 @@
 One "step" = one optimizer step on one batch of synthetic dialogues already resident in HBM:
 forward + criterion + backward (one hipGraph launch), gradient all-reduce over RCCL when N > 1, fused Adam.
 The headline metric (BASELINE.json) is utterances/s; per-GPU work is fixed (weak scaling, global batch = N * B).
-Workload = BASELINE.json configs[1] ("c2": shipped depth, roberta-base 768 + audio_mel 300, B=32 x L=16, bf16).
+Workload = BASELINE.json configs[2] ("c3": shipped depth, roberta-large 1024 + wav2vec2 768, B=64 x L=16, bf16) - the largest
+single-GPU configuration and the one north_star's target is stated on; configs[1] ("c2") runs with --workload c2.
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel = the grouped MFMA GEMM,
 timed live with hipEvents per launch) and `cpu_baseline` (the CPU oracle on the host cores, N=1 only).
 """
@@ -114,7 +115,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("M2F_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("M2F_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=os.environ.get("M2F_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="secondary workload of SURVEY 8-d: MELD-like dialogue lengths, "

@@ -19,6 +19,12 @@
 #include "common.h"
 #include "ops.h"
 
+// No floating-point contraction in this file: the launch-list kernels and the persistent kernel (mega.hip) restate the same
+// formulas in different surroundings, and with -ffp-contract=fast (the HIP default) the compiler is free to fuse a*b+c in one
+// of them and not in the other - a 1-ulp difference that would hide real hand-off bugs from the bit-for-bit comparison of
+// the two paths (tests/test_mega_gpu.py).  These kernels are bound by memory or by MFMA, not by VALU multiplies.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int NTHR = 256;          // 4 wavefronts per (dialogue, head)

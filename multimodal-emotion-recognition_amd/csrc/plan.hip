@@ -17,6 +17,7 @@
 #include "../../include/m2fnet_hip.h"
 #include "common.h"
 #include "ops.h"
+#include "mega.h"
 
 #include <algorithm>
 #include <cmath>
@@ -242,6 +243,11 @@ struct m2f_plan {
     GemmBatch wg_tab;
     double wg_flops = 0.0;
     std::vector<LnReduceBatch> lnred;
+    // strip-dataflow persistent kernels (mega.h, bf16 mode): the whole forward launch list, and the backward list from
+    // `first` on, as ONE launch each.  M2F_MEGA=0 (read when a plan is built) keeps the launch lists.
+    struct MegaRun { MegaArgs args; bool on = false; int nt = 0, grid = 0, n_ops = 0; size_t first = 0; double flops = 0.0; size_t zero_bytes = 0; };
+    MegaRun mfwd, mbwd;
+    uint32_t* mega_status = nullptr;     // [8]: sticky give-up record of the two runs (zeroed when the plan is created)
     size_t ws_used = 0;
     // graph cache for m2f_step
     hipGraphExec_t gexec = nullptr;
@@ -776,6 +782,202 @@ void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Laun
     }
 }
 
+
+// ---- strip-dataflow persistent kernel: item / problem / target tables of one launch list (mega.h) -------------------
+struct MegaTables {
+    std::vector<MegaItem> items;
+    std::vector<GemmProblem> gemm;
+    std::vector<AttnProblem> attn;
+    std::vector<LnProblem> ln;
+    std::vector<MegaDrop> drop;
+    std::vector<uint32_t> need;      // [n_ops][n_strips]
+    int n_ops = 0;
+    double flops = 0.0;
+    bool eligible = true;            // every op can run inside the kernel (decided on the real pointers, not in the dry sizing pass)
+};
+
+// Rewrites a chain GEMM problem into the k-contiguous bf16 form the kernel stages (forward: W shadow; input gradient: the
+// W^T shadow).  false: an operand has no 16-byte-stageable bf16 copy (e.g. the [T, n_classes] criterion gradient).
+bool mega_gemm_form(GemmProblem& g, int layout, int T) {
+    if (layout == M2F_LAYOUT_TN || g.M != T) return false;
+    if (layout == M2F_LAYOUT_NN)
+        for (int sgm = 0; sgm < 2; ++sgm) { g.b.q[sgm] = g.b.qt[sgm]; g.b.ldq[sgm] = g.b.ldqt[sgm]; }
+    if (g.a.k[0] != g.b.k[0] || g.a.k[1] != g.b.k[1] || g.a.k[0] <= 0) return false;
+    if ((g.flags & (GF_GELU_OUT | GF_RELU_B)) || g.c8 || g.bias_grad) return false;
+    auto seg_ok = [](const GemmOperand& o) {
+        for (int sgm = 0; sgm < 2; ++sgm) {
+            if (o.k[sgm] == 0) continue;
+            if (!o.q[sgm] || (reinterpret_cast<uintptr_t>(o.q[sgm]) & 15) || (o.ldq[sgm] & 7)) return false;
+            if ((o.k[sgm] & 7) && o.ldq[sgm] != ((o.k[sgm] + 7) & ~7)) return false;      // the pads must be the buffer's own zero pads
+            if (o.ldq[sgm] < o.k[sgm]) return false;
+        }
+        return true;
+    };
+    return seg_ok(g.a) && seg_ok(g.b);
+}
+
+void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first, int halves_fwd, int halves_bwd, MegaTables& mt) {
+    const int T = P.T, L = P.L, S = M2F_MEGA_STRIP, n_strips = (T + S - 1) / S;
+    std::vector<uint32_t> done((size_t)n_strips, 0u);          // items of the earlier ops per strip
+    auto pad8 = [&]() { while (mt.items.size() & 7) { MegaItem z; memset(&z, 0, sizeof(z)); mt.items.push_back(z); } };
+    for (size_t li = first; li < ls.size(); ++li) {
+        const Launch& l = ls[li];
+        const int op = mt.n_ops++;
+        for (int s = 0; s < n_strips; ++s) mt.need.push_back(done[s]);
+        std::vector<uint32_t> mine((size_t)n_strips, 0u);
+        auto push = [&](int kind, int prob, int a, int b, int tok_lo, int tok_hi) {
+            MegaItem it; memset(&it, 0, sizeof(it));
+            it.kind = (uint8_t)kind; it.op = (uint16_t)op; it.prob = (uint16_t)prob; it.a = a; it.b = b;
+            const int s0 = tok_lo / S, s1 = std::min(tok_hi, T - 1) / S;
+            it.s0 = (uint16_t)s0; it.nstrips = (uint8_t)(s1 - s0 + 1);
+            for (int s = s0; s <= s1; ++s) ++mine[s];
+            mt.items.push_back(it);
+        };
+        if (op > 65535) mt.eligible = false;
+        switch (l.kind) {
+            case OP_GEMM: {
+                // panels (problem, 64-column block) are dealt round-robin to the 8 XCDs: item index = panel mod 8 (mod 8), so
+                // with a grid that is a multiple of 8 a weight panel is pulled into ONE L2 (placement changes speed only)
+                std::vector<std::pair<int, int>> panels;
+                for (int i = 0; i < l.gb.count; ++i) {
+                    GemmProblem g = l.gb.pr[i];
+                    if (!mega_gemm_form(g, l.layout, T)) mt.eligible = false;
+                    mt.flops += 2.0 * g.M * g.N * ((double)g.a.k[0] + g.a.k[1]);
+                    const int prob = (int)mt.gemm.size();
+                    mt.gemm.push_back(g);
+                    for (int np = 0; np < (g.N + 63) / 64; ++np) panels.push_back({prob, np});
+                }
+                if (mt.gemm.size() > 65535) mt.eligible = false;
+                for (size_t g0 = 0; g0 < panels.size(); g0 += 8)
+                    for (int ms = 0; ms < n_strips; ++ms)
+                        for (size_t x = 0; x < 8; ++x) {
+                            if (g0 + x < panels.size()) push(MK_GEMM, panels[g0 + x].first, 64 * ms, 64 * panels[g0 + x].second, S * ms, S * ms + S - 1);
+                            else { MegaItem z; memset(&z, 0, sizeof(z)); mt.items.push_back(z); }
+                        }
+                break;
+            }
+            case OP_ATTN_FWD: case OP_ATTN_BWD: {
+                const int halves = l.kind == OP_ATTN_FWD ? halves_fwd : halves_bwd;
+                for (int i = 0; i < l.ab.count; ++i) {
+                    const AttnProblem& ap = l.ab.pr[i];
+                    const int prob = (int)mt.attn.size();
+                    mt.attn.push_back(ap);
+                    const int nbh = P.B * ap.H;
+                    for (int bh0 = 0; bh0 < nbh; bh0 += halves) {
+                        const int cnt = std::min(halves, nbh - bh0);
+                        push(l.kind == OP_ATTN_FWD ? MK_ATTN_FWD : MK_ATTN_BWD, prob, bh0, cnt, (bh0 / ap.H) * L, ((bh0 + cnt - 1) / ap.H + 1) * L - 1);
+                    }
+                }
+                break;
+            }
+            case OP_LN_FWD: case OP_LN_BWD: {
+                for (int i = 0; i < l.lb.count; ++i) {
+                    if (l.lb.pr[i].d > M2F_MEGA_MAX_D) mt.eligible = false;
+                    const int prob = (int)mt.ln.size();
+                    mt.ln.push_back(l.lb.pr[i]);
+                    const int nblk = m2f_ln_row_blocks(T);
+                    for (int b0 = 0; b0 < nblk; b0 += 2)
+                        push(l.kind == OP_LN_FWD ? MK_LN_FWD : MK_LN_BWD, prob, b0, std::min(2, nblk - b0), b0 * M2F_LN_ROWS_PER_BLOCK,
+                             (b0 + 2) * M2F_LN_ROWS_PER_BLOCK - 1);
+                }
+                break;
+            }
+            case OP_DROPOUT: {
+                MegaDrop d; d.x = l.dptr; d.T = l.dT; d.d = l.dd; d.ld = l.dld; d.site = l.dsite;
+                const int prob = (int)mt.drop.size();
+                mt.drop.push_back(d);
+                for (int r0 = 0; r0 < l.dT; r0 += S) push(MK_DROPOUT, prob, r0, std::min(S, l.dT - r0), r0, r0 + S - 1);
+                break;
+            }
+        }
+        pad8();
+        for (int s = 0; s < n_strips; ++s) done[s] += mine[s];
+    }
+    if (mt.attn.size() > 65535 || mt.ln.size() > 65535) mt.eligible = false;
+}
+
+// Allocates the device tables of one run in the arena (same sizes in the dry sizing pass) and, with real pointers, uploads
+// them and fills run.args.
+void mega_place(m2f_plan& P, Arena& ar, bool real, const MegaTables& mt, m2f_plan::MegaRun& run, size_t first, int attn_w,
+                int bwd_fast, int halves_fwd, int halves_bwd, uint32_t* status) {
+    const int n_strips = (P.T + M2F_MEGA_STRIP - 1) / M2F_MEGA_STRIP;
+    MegaItem* d_items = ar.alloc<MegaItem>(mt.items.size() + 1);
+    GemmProblem* d_gemm = ar.alloc<GemmProblem>(mt.gemm.size() + 1);
+    AttnProblem* d_attn = ar.alloc<AttnProblem>(mt.attn.size() + 1);
+    LnProblem* d_ln = ar.alloc<LnProblem>(mt.ln.size() + 1);
+    MegaDrop* d_drop = ar.alloc<MegaDrop>(mt.drop.size() + 1);
+    uint32_t* d_need = ar.alloc<uint32_t>(mt.need.size() + 1);
+    uint32_t* d_progress = ar.alloc<uint32_t>((size_t)n_strips * 32);
+    run.on = false;
+    if (!real || !mt.eligible || mt.items.empty()) return;
+    bool ok = true;
+    auto up = [&](void* dst, const void* src, size_t bytes) { if (bytes) ok = ok && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    up(d_items, mt.items.data(), mt.items.size() * sizeof(MegaItem));
+    up(d_gemm, mt.gemm.data(), mt.gemm.size() * sizeof(GemmProblem));
+    up(d_attn, mt.attn.data(), mt.attn.size() * sizeof(AttnProblem));
+    up(d_ln, mt.ln.data(), mt.ln.size() * sizeof(LnProblem));
+    up(d_drop, mt.drop.data(), mt.drop.size() * sizeof(MegaDrop));
+    up(d_need, mt.need.data(), mt.need.size() * sizeof(uint32_t));
+    if (!ok) return;
+    MegaArgs& a = run.args;
+    memset(&a, 0, sizeof(a));
+    a.items = d_items; a.item_begin = 0; a.item_end = (int)mt.items.size(); a.n_strips = n_strips;
+    a.gemm = d_gemm; a.attn = d_attn; a.ln = d_ln; a.drop = d_drop; a.need = d_need; a.progress = d_progress; a.status = status;
+    a.B = P.B; a.L = P.L; a.T = P.T; a.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
+    a.rng = P.rng; a.drop_thresh = P.drop_thresh; a.drop_scale = P.drop_scale; a.ln_eps = P.cfg.ln_eps; a.sh = P.sh;
+    a.attn_w = attn_w; a.attn_bwd_fast = bwd_fast; a.attn_halves_fwd = halves_fwd; a.attn_halves_bwd = halves_bwd;
+    run.on = true; run.nt = (P.L + 15) / 16; run.grid = 256; run.n_ops = mt.n_ops; run.first = first; run.flops = mt.flops;
+    run.zero_bytes = (size_t)n_strips * 32 * sizeof(uint32_t);
+}
+
+void build_mega(m2f_plan& P, Arena& ar, bool real) {
+    const char* env = getenv("M2F_MEGA");
+    const bool want = M2F_MEGA_DEFAULT ? !(env && env[0] == '0') : (env && env[0] == '1');
+    const int NT = (P.L + 15) / 16, Lp = 16 * NT;
+    int W = 16;
+    for (const std::vector<Launch>* ls : {&P.fwd, &P.bwd})
+        for (const Launch& l : *ls)
+            if (l.kind == OP_ATTN_FWD || l.kind == OP_ATTN_BWD)
+                for (int i = 0; i < l.ab.count; ++i) W = std::max(W, (l.ab.pr[i].hd + 15) & ~15);
+    const size_t hf = (size_t)3 * Lp * (W + 2) * sizeof(float);
+    // same rule as attention.hip's launcher, so both paths take the same backward form
+    const int bwd_fast = (W <= 128 && ((size_t)5 * Lp * (W + 2) + Lp) * sizeof(float) <= 160 * 1024) ? 1 : 0;
+    const size_t hb = ((size_t)(bwd_fast ? 5 : 4) * Lp * (W + 2) + Lp) * sizeof(float);
+    const int halves_fwd = 2 * hf <= M2F_MEGA_LDS_WORK ? 2 : 1, halves_bwd = 2 * hb <= M2F_MEGA_LDS_WORK ? 2 : 1;
+    const bool fits = NT <= M2F_MEGA_MAX_NT && hf <= M2F_MEGA_LDS_WORK && hb <= M2F_MEGA_LDS_WORK;
+    uint32_t* status = ar.alloc<uint32_t>(16);
+    P.mega_status = status;
+    const bool use = real && want && fits && P.prec == M2F_PREC_BF16;
+    {
+        MegaTables mt;
+        mega_tables(P, P.fwd, 0, halves_fwd, halves_bwd, mt);
+        mega_place(P, ar, use, mt, P.mfwd, 0, W, bwd_fast, halves_fwd, halves_bwd, status);
+    }
+    if (P.train) {
+        // the longest tail of the backward list whose every op can run inside the kernel (the head - the input gradient of
+        // the last classifier layer, whose operand is the unshadowed [T, n_classes] criterion gradient - stays a launch)
+        size_t first = P.bwd.size();
+        if (use) {
+            while (first > 0) {
+                const Launch& l = P.bwd[first - 1];
+                bool ok = true;
+                if (l.kind == OP_GEMM)
+                    for (int i = 0; i < l.gb.count; ++i) { GemmProblem g = l.gb.pr[i]; ok = ok && mega_gemm_form(g, l.layout, P.T); }
+                if (l.kind == OP_LN_FWD || l.kind == OP_LN_BWD)
+                    for (int i = 0; i < l.lb.count; ++i) ok = ok && l.lb.pr[i].d <= M2F_MEGA_MAX_D;
+                if (!ok) break;
+                --first;
+            }
+        } else {
+            first = std::min<size_t>(P.bwd.size(), 1);       // sizing pass: every op after the first (an upper bound of the tables)
+        }
+        MegaTables mt;
+        mega_tables(P, P.bwd, first, halves_fwd, halves_bwd, mt);
+        mega_place(P, ar, use && first < P.bwd.size(), mt, P.mbwd, first, W, bwd_fast, halves_fwd, halves_bwd, status + 4);
+    }
+    if (real && status) (void)hipMemset(status, 0, 16 * sizeof(uint32_t));
+}
+
 int build_plan(m2f_plan& P, char* ws_base) {
     const m2f_config& c = P.cfg;
     Builder bld(P);
@@ -967,6 +1169,8 @@ int build_plan(m2f_plan& P, char* ws_base) {
         }
         flush();
     }
+    build_mega(P, bld.ar, ws_base != nullptr);
+    P.ws_used = bld.ar.off;
     return 0;
 }
 
@@ -1037,9 +1241,21 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
     return 0;
 }
 
+// One persistent launch in place of a launch list (mega.h): re-arm the strip counters, then the kernel.
+int run_mega(m2f_plan::MegaRun& run, int prof_kind, hipStream_t s) {
+    if (g_prof) g_prof->begin(prof_kind, run.flops);
+    M2F_HIP(hipMemsetAsync(run.args.progress, 0, run.zero_bytes, s));
+    M2F_HIP(m2f_launch_mega(run.args, run.nt, run.grid, s));
+    if (g_prof) g_prof->end();
+    return 0;
+}
+
 int do_backward(m2f_plan& P, hipStream_t s) {
     if (!P.train || !P.grads) return fail("m2f_backward: plan was created without train=1 / gradient buffer");
-    if (int r = run_launches(P, P.bwd, s)) return r;
+    if (P.mbwd.on) {
+        if (int r = run_launches(P, P.bwd, s, 0, P.mbwd.first)) return r;
+        if (int r = run_mega(P.mbwd, 12, s)) return r;
+    } else if (int r = run_launches(P, P.bwd, s)) return r;
     if (P.wg_nt) {
         if (g_prof) g_prof->begin(10, 0.0);
         M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
@@ -1128,6 +1344,14 @@ m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, in
         fail("params / grads / workspace must be 256-byte aligned"); delete p; return nullptr;
     }
     p->params = params; p->grads = grads; p->rng = rng_state;
+    {   // size the workspace with a dry build BEFORE anything is written into it
+        const int64_t need = m2f_workspace_bytes(cfg, B, L, train);
+        if (need < 0 || need > workspace_bytes) {
+            fail("workspace too small: need " + std::to_string(need) + " bytes");
+            delete p;
+            return nullptr;
+        }
+    }
     build_plan(*p, static_cast<char*>(workspace));
     if ((int64_t)p->ws_used > workspace_bytes) {
         fail("workspace too small: need " + std::to_string(p->ws_used) + " bytes");
@@ -1144,10 +1368,25 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
     return plan->bufs[which];
 }
 
+int m2f_plan_persistent(m2f_plan* plan) { return (plan->mfwd.on ? 1 : 0) | (plan->mbwd.on ? 2 : 0); }
+
+int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
+    for (int i = 0; i < 8; ++i) out8[i] = 0u;
+    if (!plan->mega_status || !(plan->mfwd.on || plan->mbwd.on)) return 0;
+    M2F_HIP(hipMemcpy(out8, plan->mega_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (out8[0] || out8[4]) {
+        const int w = out8[0] ? 0 : 4;
+        return fail(std::string("persistent ") + (w ? "backward" : "forward") + " kernel gave up (code " + std::to_string(out8[w]) +
+                    "): item " + std::to_string(out8[w + 1]) + " waited on strip " + std::to_string(out8[w + 2]) + " at " +
+                    std::to_string(out8[w + 3]));
+    }
+    return 0;
+}
+
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
-    if (phase == 0) return (int)(plan->fwd.size() + plan->casts.size());
+    if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + plan->casts.size());
     if (phase == 1) return 2;
-    return (int)(plan->bwd.size() + (plan->wg_nt ? 2 : plan->wg.size()) + plan->lnred.size());
+    return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? 2 : plan->wg.size()) + plan->lnred.size());
 }
 
 static int do_forward(m2f_plan& P, hipStream_t s) {
@@ -1156,6 +1395,7 @@ static int do_forward(m2f_plan& P, hipStream_t s) {
         M2F_HIP(m2f_launch_cast(cb, s));
         if (g_prof) g_prof->end();
     }
+    if (P.mfwd.on) return run_mega(P.mfwd, 11, s);
     return run_launches(P, P.fwd, s);
 }
 

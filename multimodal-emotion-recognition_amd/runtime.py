@@ -61,6 +61,8 @@ SIGNATURES = {
     "m2f_plan_destroy": (None, [c_void_p]),
     "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
     "m2f_plan_num_launches": (c_int, [c_void_p, c_int]),
+    "m2f_plan_persistent": (c_int, [c_void_p]),
+    "m2f_plan_status": (c_int, [c_void_p, ctypes.POINTER(c_uint32)]),
     "m2f_forward": (c_int, [c_void_p, c_void_p]),
     "m2f_loss": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),
     "m2f_backward": (c_int, [c_void_p, c_void_p]),
@@ -183,6 +185,9 @@ class Plan:
         if nbytes < 0:
             raise HipError(lib().m2f_last_error().decode())
         self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=params.device)
+        # the zero-fill runs on torch's current stream, m2f_plan_create uploads its tables with blocking copies on the
+        # null stream: order the two whatever stream context the caller is in
+        torch.cuda.current_stream(params.device).synchronize()
         base = self.workspace.data_ptr()
         self._ws_off = (-base) % 256
         self._keep = (params, grads, rng_state)
@@ -220,6 +225,15 @@ class Plan:
             n *= s
         esize = torch.empty(0, dtype=dtype).element_size()
         return self.workspace[off: off + n * esize].view(dtype).view(*shape)
+
+    def persistent(self) -> int:
+        """bit 0 / bit 1: the forward / backward chain runs as one persistent strip-dataflow launch (csrc/mega.h)."""
+        return lib().m2f_plan_persistent(self.handle)
+
+    def check_status(self) -> None:
+        """Raises if a persistent kernel gave up on a bounded wait (synchronises with the device)."""
+        out = (c_uint32 * 8)()
+        check(lib().m2f_plan_status(self.handle, out), "m2f_plan_status")
 
     def num_launches(self) -> Dict[str, int]:
         return {k: lib().m2f_plan_num_launches(self.handle, i) for i, k in enumerate(("forward", "loss", "backward"))}

@@ -1,0 +1,98 @@
+"""The strip-dataflow persistent kernels (csrc/mega.hip) against the launch-list path they replace.
+
+Both paths run the same arithmetic in the same order (same MFMA k order, same epilogue formula, same dropout RNG), so in
+bf16 mode the persistent forward / backward kernels must reproduce the launch lists BIT FOR BIT: logits, loss and every
+parameter gradient.  Any lost hand-off between workgroups (a stale read, a missed dependency) shows up as a difference -
+the comparison is repeated so that different dispatch timings are sampled.  The launch-list path itself is pinned to the
+oracle / the reference's fixtures by tests/test_model_gpu.py.
+"""
+import os
+
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, sd, mega, precision="bf16"):
+    from mer_amd.model import M2FNet
+    m = M2FNet(cfg, precision=precision)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0").train()
+    m._want_mega = mega
+    return m
+
+
+def _step(model, batch, use_graph=False):
+    text, audio, key_pad, emotion = batch
+    os.environ["M2F_MEGA"] = "1" if model._want_mega else "0"          # read when a plan is built (first step)
+    loss = model.train_step(text, audio, key_pad, emotion, use_graph=use_graph)
+    torch.cuda.synchronize()
+    eng = model.engine()
+    plan = next(iter(eng.plans.values()))
+    plan.check_status()
+    return plan.loss.clone(), plan.logits.clone(), eng.flat_grad.clone(), plan
+
+
+def _cases():
+    full = synth._cfg
+    return {
+        "tiny_ragged": synth.CASES["tiny_ragged"][:4],
+        "tiny_shared_norm": synth.CASES["tiny_shared_norm"][:4],
+        "tiny_no_fam": synth.CASES["tiny_no_fam"][:4],
+        "tiny_audio_only": synth.CASES["tiny_audio_only"][:4],
+        "c2_slice": synth.CASES["c2_slice"][:4],
+        # partial strips (T = 21), two 16-row attention tiles (L = 24), dialogues straddling 64-token strips
+        "odd_T": (full(48, 64, 64, 4, 4, 4, 1, 1, 1), 3, 7, [7, 2, 5]),
+        "L24": (full(96, 128, 64, 4, 8, 4, 1, 2, 2), 7, 24, [24, 3, 17, 24, 9, 1, 20]),
+        "c3_slice": (full(768, 1024, 768, 8, 8, 8, 1, 1, 2), 8, 16, None),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_cases()))
+@pytest.mark.parametrize("dropout", [0.0, 0.4])
+def test_persistent_kernels_equal_launch_lists_bit_for_bit(name, dropout):
+    cfg, B, L, lengths = _cases()[name]
+    cfg = dict(cfg, dropout=dropout)
+    sd = synth.make_state_dict(cfg)
+    batch = [t.cuda() for t in synth.make_inputs(cfg, B, L, lengths, "randn")]
+    torch.manual_seed(5)
+    ref = _model(cfg, sd, mega=False)
+    torch.manual_seed(5)                                   # same dropout RNG state in both engines
+    new = _model(cfg, sd, mega=True)
+    l0, z0, g0, p0 = _step(ref, batch)
+    assert p0.persistent() == 0
+    for rep in range(3):
+        l1, z1, g1, p1 = _step(new, batch)
+        assert p1.persistent() == 3, "the persistent kernels did not engage"
+        if rep == 0:
+            assert torch.equal(z0, z1), f"logits differ: max {(z0 - z1).abs().max().item()}"
+            assert torch.equal(l0[:3], l1[:3])
+            bad = (g0 != g1)
+            assert not bad.any(), f"{int(bad.sum())} gradient elements differ, max {(g0 - g1).abs().max().item()}"
+        if dropout == 0.0:                                 # the RNG state advances per step: only p = 0 repeats exactly
+            assert torch.equal(z0, z1) and torch.equal(g0, g1)
+    os.environ.pop("M2F_MEGA", None)
+
+
+def test_persistent_kernels_full_bench_geometry_and_graph_replay():
+    """BASELINE C2 at full size (B=32 x L=16, 6+6+5 layers): persistent kernels == launch lists, eager and as hipGraph."""
+    import bench
+    wl = bench.WORKLOADS["c2"]
+    cfg, B, L = dict(wl["cfg"], dropout=0.0), wl["B"], wl["L"]
+    torch.manual_seed(0)
+    sd = synth.make_state_dict(cfg)
+    batch = list(bench.synthetic_batch(cfg, B, L, 0, "cuda:0", ragged=True))
+    batch = [batch[0], batch[1], batch[2], batch[3]]
+    ref = _model(cfg, sd, mega=False)
+    new = _model(cfg, sd, mega=True)
+    l0, z0, g0, _ = _step(ref, batch)
+    l1, z1, g1, p1 = _step(new, batch)
+    assert p1.persistent() == 3
+    assert torch.equal(z0, z1) and torch.equal(g0, g1) and torch.equal(l0[:3], l1[:3])
+    for _ in range(5):                                     # capture + replays
+        l2, z2, g2, _ = _step(new, batch, use_graph=True)
+        assert torch.equal(z0, z2) and torch.equal(g0, g2)
+    os.environ.pop("M2F_MEGA", None)

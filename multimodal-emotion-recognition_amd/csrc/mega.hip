@@ -34,7 +34,7 @@ constexpr int MG_BM = 64, MG_BK = 128;                  // tile 64 x 64, k-tiles
 // swizzle is applied to the per-lane SOURCE address and undone by the fragment reads (cdna_hip_programming.md rule 21);
 // a 16-lane group of ds_read_b128 then touches 16 different positions = all 64 banks: conflict-free.
 constexpr int MG_TILE = MG_BM * MG_BK * 2;              // 16 KB per operand tile
-constexpr int MG_NBUF = 3;                              // ring: one tile being multiplied, one landed or landing, one in flight
+constexpr int MG_NBUF = 4;                              // ring: one tile being multiplied, three landed or in flight
 constexpr int LDS_MISC_BYTES = 256;
 constexpr int LDS_EP_STRIDE = 36;                          // floats per row of a consumer wave's 32x32 epilogue image
 constexpr int LDS_EP_BYTES = 4 * 32 * LDS_EP_STRIDE * 4;
@@ -42,7 +42,7 @@ constexpr int LDS_MISC_OFF = M2F_MEGA_LDS - LDS_MISC_BYTES;
 constexpr int LDS_EP_OFF = LDS_MISC_OFF - LDS_EP_BYTES;    // [0, LDS_EP_OFF): GEMM operand rings | attention slabs | LN partials
 static_assert(LDS_EP_OFF == M2F_MEGA_LDS_WORK, "mega.h");
 static_assert(2 * MG_NBUF * MG_TILE <= LDS_EP_OFF, "LDS budget");
-enum { MISC_ABORT = 0, MISC_EPOCH = 1, MISC_ARRIVE4 = 2, MISC_ARRIVE8 = 3 };
+enum { MISC_ABORT = 0, MISC_EPOCH = 1, MISC_ARRIVE4 = 2, MISC_ARRIVE8 = 3, MISC_TICKET = 4 /* and 5: ticket of the item after this one, by parity */ };
 
 // give-up codes in status[0]
 enum { MEGA_OK = 0, MEGA_TIMEOUT = 1 };
@@ -87,6 +87,17 @@ __device__ __forceinline__ void lds_store_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+#ifdef M2F_MEGA_PROF
+// diagnostic build: ticks of s_memrealtime (100 MHz) per item phase, summed per kind (never in the shipped library)
+#define PROF_NOW() __builtin_amdgcn_s_memrealtime()
+__device__ __forceinline__ void prof_add(const MegaArgs& a, int kind, int field, unsigned long long v) {
+    if (a.prof) atomicAdd(a.prof + kind * 8 + field, v);
+}
+#else
+#define PROF_NOW() 0ull
+__device__ __forceinline__ void prof_add(const MegaArgs&, int, int, unsigned long long) {}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // dependency protocol
 // ---------------------------------------------------------------------------------------------------------
@@ -127,10 +138,19 @@ __device__ __forceinline__ void mega_arrive(const MegaArgs& a, const MegaItem& i
         }
     }
 }
-// All-wave items: wave 4 polls, everybody meets at a barrier.  false = the launch has given up (uniform for the workgroup).
-__device__ __forceinline__ bool mega_wait_all(const MegaArgs& a, const MegaItem& it, int idx, unsigned* misc, int wave, int lane) {
+// Ticket of the workgroup's NEXT item: drawn by wave 4 / lane 0 at the start of the current item (the atomic's latency hides
+// behind the item), published in LDS before the first barrier of the current item, read by every wave at the next loop top.
+__device__ __forceinline__ unsigned mega_draw(const MegaArgs& a, int xcc) {
+    return __hip_atomic_fetch_add(a.queue + 32 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All-wave items: wave 4 draws the next ticket and polls, everybody meets at a barrier.  false = the launch has given up
+// (uniform for the workgroup).
+__device__ __forceinline__ bool mega_wait_all(const MegaArgs& a, const MegaItem& it, int idx, unsigned* misc, int wave, int lane,
+                                              int xcc, unsigned nth) {
     if (wave == 4 && lane == 0) {
+        const unsigned tn = mega_draw(a, xcc);
         if (lds_load_u32(misc + MISC_ABORT) == 0u && !mega_poll(a, it, idx)) lds_store_u32(misc + MISC_ABORT, 1u);
+        lds_store_u32(misc + MISC_TICKET + ((nth + 1u) & 1u), tn);
     }
     __syncthreads();
     return lds_load_u32(misc + MISC_ABORT) == 0u;
@@ -155,10 +175,25 @@ __device__ __forceinline__ float ep_value(float acc, float bias, float res, floa
     return x + cprev;
 }
 
-// returns false when the launch has given up (decided by wave 4 BEFORE it arrived at barrier B0: every wave reads the
-// word right behind B0, so the whole workgroup leaves at the same point)
+// The consumers' view of an item whose epilogue stores have been issued but not yet published
+struct Pending { int s0, nstrips; bool on; };
+__device__ __forceinline__ void mega_flush(const MegaArgs& a, Pending& pd, unsigned* misc, int lane) {
+    if (!pd.on) return;                                          // uniform for the consumer waves
+    MegaItem it; it.s0 = (uint16_t)pd.s0; it.nstrips = (uint8_t)pd.nstrips;
+    mega_arrive(a, it, misc + MISC_ARRIVE4, 3u, lane);
+    pd.on = false;
+}
+
+// Consumers (waves 0-3).  returns false when the launch has given up (decided by wave 4 BEFORE it published the epoch
+// word and arrived at barrier B0: every wave reads the abort word behind B0, so the whole workgroup leaves at the same point).
+//
+// Publishing an item needs every storing wave to drain its write-through stores (s_waitcnt vmcnt(0): ~3 us of memory
+// round trip).  The drain is DEFERRED while the workgroup has work: the stores of item i are left in flight, the waves go
+// on to item i+1 and publish i after i+1's k-loop, when the drain is free.  While the workgroup is stalled - the
+// producers' poll for i+1 has not come through - the pending item is published at once, which also covers the case that
+// i+1 depends on i itself (same strip, next op): no deadlock, and a latency-bound chain is not slowed down.
 __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const MegaItem& it, const GemmProblem& P, char* smem,
-                                                   unsigned* misc, int wave, int lane) {
+                                                   unsigned* misc, int wave, int lane, unsigned seq, Pending& pd) {
     const int m0 = it.a, n0 = it.b;
     const int M = P.M, N = P.N;
     const int nk = (P.a.k[0] + MG_BK - 1) / MG_BK + (P.a.k[1] + MG_BK - 1) / MG_BK;
@@ -166,11 +201,51 @@ __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const Mega
     const char* ldsA = smem;
     const char* ldsB = smem + MG_NBUF * MG_TILE;
     const bool reluA = P.flags & GF_RELU_A;
+    const unsigned long long t_top = PROF_NOW();
+    // ---- wait until the producers' dependency poll for this item is through; publish the pending item meanwhile -----
+    while (lds_load_u32(misc + MISC_EPOCH) < seq) {
+        if (pd.on) mega_flush(a, pd, misc, lane);
+        else __builtin_amdgcn_s_sleep(1);
+    }
+    // ---- epilogue operands (residual / ReLU gate / accumulate): requested now, consumed after the k-loop -----------
+    const unsigned flags = P.flags;
+    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
+    const float* __restrict__ bias = P.bias;
+    const bool has_res = P.res != nullptr, has_gate = P.gate != nullptr;
+    const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
+    const float gscale = P.gate_scale;
+    const unsigned site = P.drop_site;
+    uint16_t* c16p = (ldc & 7) ? nullptr : m2f_shadow_of(a.sh, P.c);
+    const rsrc_t rc = mk_rsrc(P.c);
+    const rsrc_t rres = mk_rsrc(has_res ? P.res : P.c);
+    const rsrc_t rgate = mk_rsrc(has_gate ? P.gate : P.c);
+    const rsrc_t rc16 = mk_rsrc(c16p ? (const void*)c16p : (const void*)P.c);
+    const bool al = ((reinterpret_cast<uintptr_t>(P.c) & 15) == 0) && ((ldc & 3) == 0) &&
+                    (!has_res || (((reinterpret_cast<uintptr_t>(P.res) & 15) == 0) && ((ldres & 3) == 0))) &&
+                    (!has_gate || (((reinterpret_cast<uintptr_t>(P.gate) & 15) == 0) && ((ldgate & 3) == 0))) &&
+                    (!c16p || ((reinterpret_cast<uintptr_t>(c16p) & 15) == 0));
+    const int c8 = 8 * (lane & 3);
+    const int col = n0 + wn * 32 + c8;
+    const bool vec_lane = al && col + 8 <= N;
+    f32x4 pre[2][6];                                                 // [pass][res lo, res hi, gate lo, gate hi, C lo, C hi]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = m0 + wm * 32 + (lane >> 2) + 16 * p;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) pre[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (vec_lane && row < M) {
+            const unsigned oc = (unsigned)(row * ldc + col), ores = (unsigned)(row * ldres + col), og = (unsigned)(row * ldgate + col);
+            if (has_res) { pre[p][0] = ld4(rres, ores * 4u); pre[p][1] = ld4(rres, ores * 4u + 16u); }
+            if (has_gate) { pre[p][2] = ld4(rgate, og * 4u); pre[p][3] = ld4(rgate, og * 4u + 16u); }
+            if (accum) { pre[p][4] = ld4(rc, oc * 4u); pre[p][5] = ld4(rc, oc * 4u + 16u); }
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     lds_barrier();                                                  // (B0) tile 0 has landed
     if (lds_load_u32(misc + MISC_ABORT) != 0u) return false;
+    const unsigned long long t_b0 = PROF_NOW();
     // fragment of k-slice ks: row (lane & 31) of the wave's 32-row block, chunk 2 ks + (lane >> 5), at its swizzled position
     const int x = lane & 15, h = lane >> 5;
     const int arow = (wm * 32 + (lane & 31)) * (MG_BK * 2), brow = (wn * 32 + (lane & 31)) * (MG_BK * 2);
@@ -200,6 +275,8 @@ __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const Mega
         lds_barrier();                                              // (B1 per k-tile)
         slot = slot == MG_NBUF - 1 ? 0 : slot + 1;
     }
+    const unsigned long long t_k = PROF_NOW();
+    mega_flush(a, pd, misc, lane);                                  // the previous item's stores have long landed
 
     // ---- epilogue: accumulators -> this wave's LDS image -> row-major 8-column groups -> 16-byte sc1 accesses ----------
     float* ep = reinterpret_cast<float*>(smem + LDS_EP_OFF) + wave * 32 * LDS_EP_STRIDE;
@@ -212,26 +289,8 @@ __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const Mega
     // f32x4 loads (no common type) and would hoist the loads - pin the order
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    const unsigned flags = P.flags;
-    const bool relu_out = flags & GF_RELU_OUT, accum = flags & GF_ACCUM;
-    const float* __restrict__ bias = P.bias;
-    const bool has_res = P.res != nullptr, has_gate = P.gate != nullptr;
-    const int ldc = P.ldc, ldres = P.ldres, ldgate = P.ldgate;
-    const float gscale = P.gate_scale;
-    const unsigned site = P.drop_site;
     unsigned key = 0;
     if (site) key = m2f_site_key(a.rng, site);
-    uint16_t* c16p = (ldc & 7) ? nullptr : m2f_shadow_of(a.sh, P.c);
-    const rsrc_t rc = mk_rsrc(P.c);
-    const rsrc_t rres = mk_rsrc(has_res ? P.res : P.c);
-    const rsrc_t rgate = mk_rsrc(has_gate ? P.gate : P.c);
-    const rsrc_t rc16 = mk_rsrc(c16p ? (const void*)c16p : (const void*)P.c);
-    const bool al = ((reinterpret_cast<uintptr_t>(P.c) & 15) == 0) && ((ldc & 3) == 0) &&
-                    (!has_res || (((reinterpret_cast<uintptr_t>(P.res) & 15) == 0) && ((ldres & 3) == 0))) &&
-                    (!has_gate || (((reinterpret_cast<uintptr_t>(P.gate) & 15) == 0) && ((ldgate & 3) == 0))) &&
-                    (!c16p || ((reinterpret_cast<uintptr_t>(c16p) & 15) == 0));
-    const int c8 = 8 * (lane & 3);
-    const int col = n0 + wn * 32 + c8;
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (bias && col + e < N) ? bias[col + e] : 0.f;
@@ -245,14 +304,10 @@ __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const Mega
         if (row >= M || col >= N) continue;
         const unsigned oc = (unsigned)(row * ldc + col), ores = (unsigned)(row * ldres + col), og = (unsigned)(row * ldgate + col);
         float out[8];
-        if (al && col + 8 <= N) {
-            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, g0 = r0, g1 = r0, c0 = r0, c1 = r0;
-            if (has_res) { r0 = ld4(rres, ores * 4u); r1 = ld4(rres, ores * 4u + 16u); }
-            if (has_gate) { g0 = ld4(rgate, og * 4u); g1 = ld4(rgate, og * 4u + 16u); }
-            if (accum) { c0 = ld4(rc, oc * 4u); c1 = ld4(rc, oc * 4u + 16u); }
-            const float rv[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-            const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-            const float cv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        if (vec_lane) {
+            const float rv[8] = {pre[p][0][0], pre[p][0][1], pre[p][0][2], pre[p][0][3], pre[p][1][0], pre[p][1][1], pre[p][1][2], pre[p][1][3]};
+            const float gv[8] = {pre[p][2][0], pre[p][2][1], pre[p][2][2], pre[p][2][3], pre[p][3][0], pre[p][3][1], pre[p][3][2], pre[p][3][3]};
+            const float cv[8] = {pre[p][4][0], pre[p][4][1], pre[p][4][2], pre[p][4][3], pre[p][5][0], pre[p][5][1], pre[p][5][2], pre[p][5][3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 out[e] = ep_value(xv[e], bv[e], rv[e], gv[e], cv[e], relu_out, has_gate, gscale, site, key, a.drop_thresh, a.drop_scale,
@@ -275,7 +330,14 @@ __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const Mega
             }
         }
     }
-    mega_arrive(a, it, misc + MISC_ARRIVE4, 3u, lane);
+    pd.s0 = it.s0; pd.nstrips = it.nstrips; pd.on = true;           // published later (mega_flush)
+#ifdef M2F_MEGA_PROF
+    if (wave == 0 && lane == 0) {
+        const unsigned long long t_e = PROF_NOW();
+        prof_add(a, MK_GEMM, 0, 1); prof_add(a, MK_GEMM, 1, t_e - t_top); prof_add(a, MK_GEMM, 2, t_b0 - t_top);
+        prof_add(a, MK_GEMM, 3, t_k - t_b0); prof_add(a, MK_GEMM, 4, t_e - t_k); prof_add(a, MK_GEMM, 6, (unsigned long long)nk);
+    }
+#endif
     return true;
 }
 
@@ -285,8 +347,10 @@ __device__ __forceinline__ bool mega_gemm_consumer(const MegaArgs& a, const Mega
 // land as zeros), so edge tiles need no masking pass.  The weight tiles of the first two k-tiles are requested BEFORE the
 // dependency wait (they do not depend on the predecessor), the activation tiles - sc1 loads - right after it.
 __device__ __forceinline__ bool mega_gemm_producer(const MegaArgs& a, const MegaItem& it, int idx, const GemmProblem& P, char* smem,
-                                                   unsigned* misc, int wave, int lane, unsigned seq) {
+                                                   unsigned* misc, int wave, int lane, unsigned seq, int xcc, unsigned nth) {
     typedef __attribute__((address_space(3))) void lds_void;
+    unsigned tnext = 0;
+    if (wave == 4 && lane == 0) tnext = mega_draw(a, xcc);          // the next item's ticket; lands while this item streams
     const int pw = wave - 4;
     const int m0 = it.a, n0 = it.b;
     const int M = P.M, N = P.N;
@@ -326,14 +390,27 @@ __device__ __forceinline__ bool mega_gemm_producer(const MegaArgs& a, const Mega
             }
         }
     };
-    // weights of the first two k-tiles: before the dependency wait
+    auto wait_vm = [](int n) {                                       // s_waitcnt takes an immediate
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        }
+    };
+    // weights of the first three k-tiles: before the dependency wait
     issue_op(false, 0, 0);
     if (nk > 1) issue_op(false, 1, 1);
+    if (nk > 2) issue_op(false, 2, 2);
     // dependency: wave 4 polls the strip counters, the other producer waves wait for its LDS word
     if (wave == 4) {
         if (lane == 0) {
+            const unsigned long long t_p = PROF_NOW();
             if (lds_load_u32(misc + MISC_ABORT) == 0u && !mega_poll(a, it, idx)) lds_store_u32(misc + MISC_ABORT, 1u);
+            lds_store_u32(misc + MISC_TICKET + ((nth + 1u) & 1u), tnext);     // visible to every wave behind barrier B0
             lds_store_u32(misc + MISC_EPOCH, seq);
+            prof_add(a, MK_GEMM, 5, PROF_NOW() - t_p);
         }
     } else {
         while (lds_load_u32(misc + MISC_EPOCH) < seq) __builtin_amdgcn_s_sleep(1);
@@ -347,22 +424,21 @@ __device__ __forceinline__ bool mega_gemm_producer(const MegaArgs& a, const Mega
     }
     issue_op(true, 0, 0);
     if (nk > 1) issue_op(true, 1, 1);
-    // tile 0 complete when at most the 4 activation pieces of tile 1 are outstanding (in-order completion counting)
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk > 2) issue_op(true, 2, 2);
+    // loads complete in issue order: tile 0 is whole once only the activation pieces of tiles 1 and 2 (4 each) are outstanding
+    wait_vm((nk > 1 ? 4 : 0) + (nk > 2 ? 4 : 0));
     lds_barrier();                                                   // (B0)
-    int slot2 = 2;                                                   // ring slot of tile kt + 2
+    int slot3 = 3;                                                   // ring slot of tile kt + 3
     for (int kt = 0; kt < nk; ++kt) {
-        // the consumers multiply tile kt; slot (kt + 2) % 3 held tile kt - 1, whose reads finished before the last barrier
-        if (kt + 2 < nk) {
-            issue_op(false, kt + 2, slot2);
-            issue_op(true, kt + 2, slot2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // tile kt + 1 has landed
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // the consumers multiply tile kt; slot (kt + 3) % 4 held tile kt - 1, whose reads finished before the last barrier
+        if (kt + 3 < nk) { issue_op(false, kt + 3, slot3); issue_op(true, kt + 3, slot3); }
+        // tile kt + 1 has landed once only what was issued after its last piece is outstanding
+        int younger = (kt + 3 < nk ? 8 : 0);
+        if (kt == 0) younger += (nk > 2 ? 4 : 0);                    // prologue order: ... A1 A2
+        else younger += (kt + 2 < nk ? 8 : 0);
+        wait_vm(kt + 1 < nk ? younger : 0);
         lds_barrier();                                               // (B1 per k-tile)
-        slot2 = slot2 == MG_NBUF - 1 ? 0 : slot2 + 1;
+        slot3 = slot3 == MG_NBUF - 1 ? 0 : slot3 + 1;
     }
     return true;
 }
@@ -991,10 +1067,37 @@ __device__ __forceinline__ void mega_dropout(const MegaArgs& a, const MegaDrop& 
     const unsigned key = m2f_site_key(a.rng, D.site);
     uint16_t* x16 = m2f_shadow_of(a.sh, D.x);
     const rsrc_t rx = mk_rsrc(D.x), rx16 = mk_rsrc(x16 ? (const void*)x16 : (const void*)D.x);
-    const int n = nrows * D.d;
+    const int r1 = row0 + nrows < D.T ? row0 + nrows : D.T;
+    const bool vec = ((D.d & 3) == 0) && ((D.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(D.x) & 15) == 0) &&
+                     (!x16 || ((reinterpret_cast<uintptr_t>(x16) & 7) == 0));
+    if (vec) {
+        // four float4 per lane in flight (all loads of a batch before the first store): a 16 x 768 item is 6 such batches
+        const int c4n = D.d >> 2, n4 = (r1 - row0) * c4n;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * M2F_MEGA_THREADS) {
+            f32x4 v[4]; unsigned o[4]; unsigned flat[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * M2F_MEGA_THREADS;
+                ok[u] = i < n4;
+                const int r = row0 + (ok[u] ? i / c4n : 0), c = 4 * (ok[u] ? i % c4n : 0);
+                o[u] = (unsigned)(r * D.ld + c); flat[u] = (unsigned)(r * D.d + c);
+                v[u] = ld4(rx, o[u] * 4u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = m2f_keep(key, flat[u] + e, a.drop_thresh) ? v[u][e] * a.drop_scale : 0.f;
+                st4(rx, o[u] * 4u, w);
+                if (x16) st_u2(rx16, o[u] * 2u, (u32x2){pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3])});
+            }
+        }
+        return;
+    }
+    const int n = (r1 - row0) * D.d;
     for (int i = threadIdx.x; i < n; i += M2F_MEGA_THREADS) {
         const int r = row0 + i / D.d, c = i % D.d;
-        if (r >= D.T) break;
         const unsigned o = (unsigned)(r * D.ld + c);
         const float v = m2f_keep(key, (unsigned)(r * D.d + c), a.drop_thresh) ? ld1(rx, o * 4u) * a.drop_scale : 0.f;
         st1(rx, o * 4u, v);
@@ -1010,19 +1113,32 @@ __global__ __launch_bounds__(M2F_MEGA_THREADS) void m2f_mega_kernel(const MegaAr
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     unsigned seq = 0;                                            // GEMM items this workgroup has started
+    Pending pd; pd.s0 = 0; pd.nstrips = 0; pd.on = false;        // consumer waves: an item stored but not yet published
     constexpr int Lp = 16 * NT;
-    for (int idx = a.item_begin + (int)blockIdx.x; idx < a.item_end; idx += (int)gridDim.x) {
+    const unsigned long long t_kernel = PROF_NOW();
+    // this workgroup's queue = its XCD's (HW_REG_XCC_ID; which workgroups share an L2 is all that matters)
+    const int xcc = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u));
+    const int q0 = a.qoff[xcc];
+    const unsigned qn = (unsigned)(a.qoff[xcc + 1] - q0);
+    if (wave == 4 && lane == 0) lds_store_u32(misc + MISC_TICKET, mega_draw(a, xcc));
+    __syncthreads();
+    for (unsigned nth = 0;; ++nth) {
+        const unsigned ticket = lds_load_u32(misc + MISC_TICKET + (nth & 1u));
+        if (ticket >= qn) break;                                 // uniform: every wave reads the same word
+        const int idx = q0 + (int)ticket;
         const MegaItem it = a.items[idx];
-        if (it.kind == MK_NULL) continue;
         if (it.kind == MK_GEMM) {
             const GemmProblem& P = a.gemm[it.prob];
             ++seq;
-            const bool ok = wave >= 4 ? mega_gemm_producer(a, it, idx, P, smem, misc, wave, lane, seq)
-                                      : mega_gemm_consumer(a, it, P, smem, misc, wave, lane);
+            const bool ok = wave >= 4 ? mega_gemm_producer(a, it, idx, P, smem, misc, wave, lane, seq, xcc, nth)
+                                      : mega_gemm_consumer(a, it, P, smem, misc, wave, lane, seq, pd);
             if (!ok) return;
             continue;
         }
-        if (!mega_wait_all(a, it, idx, misc, wave, lane)) return;
+        if (wave < 4) mega_flush(a, pd, misc, lane);             // this item's poll may be waiting for it
+        const unsigned long long t_top = PROF_NOW();
+        if (!mega_wait_all(a, it, idx, misc, wave, lane, xcc, nth)) return;
+        const unsigned long long t_w = PROF_NOW();
         const int half = wave >> 2, tid = threadIdx.x & 255;
         switch (it.kind) {
             case MK_ATTN_FWD: {
@@ -1064,7 +1180,18 @@ __global__ __launch_bounds__(M2F_MEGA_THREADS) void m2f_mega_kernel(const MegaAr
         mega_arrive(a, it, misc + MISC_ARRIVE8, 7u, lane);
         // the next item's LDS writes must not overtake this item's LDS reads by slower waves
         __syncthreads();
+#ifdef M2F_MEGA_PROF
+        if (wave == 0 && lane == 0) {
+            const unsigned long long t_e = PROF_NOW();
+            prof_add(a, it.kind, 0, 1); prof_add(a, it.kind, 1, t_e - t_top); prof_add(a, it.kind, 2, t_w - t_top); prof_add(a, it.kind, 3, t_e - t_w);
+        }
+#endif
     }
+    if (wave < 4) mega_flush(a, pd, misc, lane);
+#ifdef M2F_MEGA_PROF
+    if (wave == 0 && lane == 0) { prof_add(a, 0, 0, 1); prof_add(a, 0, 1, PROF_NOW() - t_kernel); }
+    if (wave == 0 && lane == 0 && a.prof) atomicMax(a.prof + 2, PROF_NOW() - t_kernel);
+#endif
 }
 
 }  // namespace
@@ -1073,7 +1200,7 @@ hipError_t m2f_launch_mega(const MegaArgs& a, int nt, int grid, hipStream_t stre
     // NT = 3, 4 (dialogues of more than 32 utterances) are not instantiated: the five-slab attention backward spills
     // VGPRs at 256, and a spill is not allowed next to the inline-asm staging loads (check_spills.py); such plans keep
     // the launch list.
-    if (!a.items || a.item_end <= a.item_begin || grid < 1 || nt < 1 || nt > M2F_MEGA_MAX_NT) return hipErrorInvalidValue;
+    if (!a.items || !a.queue || a.qoff[8] <= 0 || grid < 1 || nt < 1 || nt > M2F_MEGA_MAX_NT) return hipErrorInvalidValue;
     void (*kern)(const MegaArgs) = nt == 1 ? m2f_mega_kernel<1> : m2f_mega_kernel<2>;
     static bool attr_set[M2F_MEGA_MAX_NT + 1] = {false, false, false};
     if (!attr_set[nt]) {

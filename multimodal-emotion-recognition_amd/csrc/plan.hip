@@ -791,6 +791,7 @@ struct MegaTables {
     std::vector<LnProblem> ln;
     std::vector<MegaDrop> drop;
     std::vector<uint32_t> need;      // [n_ops][n_strips]
+    int qoff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_ops = 0;
     double flops = 0.0;
     bool eligible = true;            // every op can run inside the kernel (decided on the real pointers, not in the dry sizing pass)
@@ -818,26 +819,37 @@ bool mega_gemm_form(GemmProblem& g, int layout, int T) {
 
 void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first, int halves_fwd, int halves_bwd, MegaTables& mt) {
     const int T = P.T, L = P.L, S = M2F_MEGA_STRIP, n_strips = (T + S - 1) / S;
+    // Item order = op-major, inside an op strip-major (a strip's share of an op finishes as early as possible, so the next
+    // op can start on it while the later strips are still being multiplied).  Optional SKEW (M2F_MEGA_GROUP = strips per
+    // group): the strips are cut into groups and time slot t lists op (t - g) of group g, so that at any moment tiles of
+    // several ops are on the chip.  Measured on MI355X (C3: 3.50 ms fwd+bwd unskewed, 3.86 / 4.01 / 4.23 with groups of
+    // 4 / 2 / 1 strips): the skew multiplies the weight traffic (a panel is re-fetched per group instead of being shared by
+    // all strips while it is hot in L2) and buys nothing, because the waits it was meant to hide are not dependency stalls
+    // (persistent kernel) - so the default is no skew.  Every order here lists an item after all items it
+    // depends on, which is all the kernel needs.
+    const char* genv = getenv("M2F_MEGA_GROUP");
+    const int gs = std::max(1, genv ? atoi(genv) : n_strips), n_groups = (n_strips + gs - 1) / gs;
     std::vector<uint32_t> done((size_t)n_strips, 0u);          // items of the earlier ops per strip
-    auto pad8 = [&]() { while (mt.items.size() & 7) { MegaItem z; memset(&z, 0, sizeof(z)); mt.items.push_back(z); } };
+    std::vector<std::vector<std::vector<std::pair<MegaItem, int>>>> chunk;     // [op][group] -> (item, queue)
+    int rr = 0;                                                // round-robin queue of the items that read no weight panel
     for (size_t li = first; li < ls.size(); ++li) {
         const Launch& l = ls[li];
         const int op = mt.n_ops++;
+        chunk.emplace_back((size_t)n_groups);
         for (int s = 0; s < n_strips; ++s) mt.need.push_back(done[s]);
         std::vector<uint32_t> mine((size_t)n_strips, 0u);
-        auto push = [&](int kind, int prob, int a, int b, int tok_lo, int tok_hi) {
+        auto push = [&](int kind, int prob, int a, int b, int tok_lo, int tok_hi, int queue) {
             MegaItem it; memset(&it, 0, sizeof(it));
             it.kind = (uint8_t)kind; it.op = (uint16_t)op; it.prob = (uint16_t)prob; it.a = a; it.b = b;
             const int s0 = tok_lo / S, s1 = std::min(tok_hi, T - 1) / S;
             it.s0 = (uint16_t)s0; it.nstrips = (uint8_t)(s1 - s0 + 1);
             for (int s = s0; s <= s1; ++s) ++mine[s];
-            mt.items.push_back(it);
+            if (queue < 0) queue = rr++ & 7;
+            chunk.back()[s1 / gs].push_back({it, queue});      // the group of its LAST strip: every strip it reads is in that group or an earlier one
         };
         if (op > 65535) mt.eligible = false;
         switch (l.kind) {
             case OP_GEMM: {
-                // panels (problem, 64-column block) are dealt round-robin to the 8 XCDs: item index = panel mod 8 (mod 8), so
-                // with a grid that is a multiple of 8 a weight panel is pulled into ONE L2 (placement changes speed only)
                 std::vector<std::pair<int, int>> panels;
                 for (int i = 0; i < l.gb.count; ++i) {
                     GemmProblem g = l.gb.pr[i];
@@ -848,12 +860,10 @@ void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first,
                     for (int np = 0; np < (g.N + 63) / 64; ++np) panels.push_back({prob, np});
                 }
                 if (mt.gemm.size() > 65535) mt.eligible = false;
-                for (size_t g0 = 0; g0 < panels.size(); g0 += 8)
-                    for (int ms = 0; ms < n_strips; ++ms)
-                        for (size_t x = 0; x < 8; ++x) {
-                            if (g0 + x < panels.size()) push(MK_GEMM, panels[g0 + x].first, 64 * ms, 64 * panels[g0 + x].second, S * ms, S * ms + S - 1);
-                            else { MegaItem z; memset(&z, 0, sizeof(z)); mt.items.push_back(z); }
-                        }
+                // a weight panel (problem, 64-column block) always goes to the same queue = the same XCD's L2
+                for (int ms = 0; ms < n_strips; ++ms)
+                    for (size_t pn = 0; pn < panels.size(); ++pn)
+                        push(MK_GEMM, panels[pn].first, 64 * ms, 64 * panels[pn].second, S * ms, S * ms + S - 1, (int)(pn & 7));
                 break;
             }
             case OP_ATTN_FWD: case OP_ATTN_BWD: {
@@ -865,7 +875,7 @@ void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first,
                     const int nbh = P.B * ap.H;
                     for (int bh0 = 0; bh0 < nbh; bh0 += halves) {
                         const int cnt = std::min(halves, nbh - bh0);
-                        push(l.kind == OP_ATTN_FWD ? MK_ATTN_FWD : MK_ATTN_BWD, prob, bh0, cnt, (bh0 / ap.H) * L, ((bh0 + cnt - 1) / ap.H + 1) * L - 1);
+                        push(l.kind == OP_ATTN_FWD ? MK_ATTN_FWD : MK_ATTN_BWD, prob, bh0, cnt, (bh0 / ap.H) * L, ((bh0 + cnt - 1) / ap.H + 1) * L - 1, -1);
                     }
                 }
                 break;
@@ -878,7 +888,7 @@ void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first,
                     const int nblk = m2f_ln_row_blocks(T);
                     for (int b0 = 0; b0 < nblk; b0 += 2)
                         push(l.kind == OP_LN_FWD ? MK_LN_FWD : MK_LN_BWD, prob, b0, std::min(2, nblk - b0), b0 * M2F_LN_ROWS_PER_BLOCK,
-                             (b0 + 2) * M2F_LN_ROWS_PER_BLOCK - 1);
+                             (b0 + 2) * M2F_LN_ROWS_PER_BLOCK - 1, -1);
                 }
                 break;
             }
@@ -886,13 +896,25 @@ void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first,
                 MegaDrop d; d.x = l.dptr; d.T = l.dT; d.d = l.dd; d.ld = l.dld; d.site = l.dsite;
                 const int prob = (int)mt.drop.size();
                 mt.drop.push_back(d);
-                for (int r0 = 0; r0 < l.dT; r0 += S) push(MK_DROPOUT, prob, r0, std::min(S, l.dT - r0), r0, r0 + S - 1);
+                for (int r0 = 0; r0 < l.dT; r0 += 16) push(MK_DROPOUT, prob, r0, std::min(16, l.dT - r0), r0, r0 + 15, -1);
                 break;
             }
         }
-        pad8();
         for (int s = 0; s < n_strips; ++s) done[s] += mine[s];
     }
+    // merge: slot t = op + group; deal the global order to the 8 queues (each queue keeps the global order)
+    std::vector<MegaItem> q[8];
+    for (int t = 0; t < mt.n_ops + n_groups - 1; ++t)
+        for (int g = 0; g < n_groups; ++g) {
+            const int op = t - g;
+            if (op < 0 || op >= mt.n_ops) continue;
+            for (const auto& e : chunk[op][g]) q[e.second].push_back(e.first);
+        }
+    for (int x = 0; x < 8; ++x) {
+        mt.qoff[x] = (int)mt.items.size();
+        mt.items.insert(mt.items.end(), q[x].begin(), q[x].end());
+    }
+    mt.qoff[8] = (int)mt.items.size();
     if (mt.attn.size() > 65535 || mt.ln.size() > 65535) mt.eligible = false;
 }
 
@@ -907,7 +929,8 @@ void mega_place(m2f_plan& P, Arena& ar, bool real, const MegaTables& mt, m2f_pla
     LnProblem* d_ln = ar.alloc<LnProblem>(mt.ln.size() + 1);
     MegaDrop* d_drop = ar.alloc<MegaDrop>(mt.drop.size() + 1);
     uint32_t* d_need = ar.alloc<uint32_t>(mt.need.size() + 1);
-    uint32_t* d_progress = ar.alloc<uint32_t>((size_t)n_strips * 32);
+    uint32_t* d_queue = ar.alloc<uint32_t>((size_t)(8 + n_strips) * 32);     // [8 ticket counters | n_strips progress counters], one 128-byte line each
+    uint32_t* d_progress = d_queue + 8 * 32;
     run.on = false;
     if (!real || !mt.eligible || mt.items.empty()) return;
     bool ok = true;
@@ -921,13 +944,14 @@ void mega_place(m2f_plan& P, Arena& ar, bool real, const MegaTables& mt, m2f_pla
     if (!ok) return;
     MegaArgs& a = run.args;
     memset(&a, 0, sizeof(a));
-    a.items = d_items; a.item_begin = 0; a.item_end = (int)mt.items.size(); a.n_strips = n_strips;
+    a.items = d_items; a.n_strips = n_strips; a.queue = d_queue;
+    for (int x = 0; x < 9; ++x) a.qoff[x] = mt.qoff[x];
     a.gemm = d_gemm; a.attn = d_attn; a.ln = d_ln; a.drop = d_drop; a.need = d_need; a.progress = d_progress; a.status = status;
     a.B = P.B; a.L = P.L; a.T = P.T; a.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
     a.rng = P.rng; a.drop_thresh = P.drop_thresh; a.drop_scale = P.drop_scale; a.ln_eps = P.cfg.ln_eps; a.sh = P.sh;
     a.attn_w = attn_w; a.attn_bwd_fast = bwd_fast; a.attn_halves_fwd = halves_fwd; a.attn_halves_bwd = halves_bwd;
     run.on = true; run.nt = (P.L + 15) / 16; run.grid = 256; run.n_ops = mt.n_ops; run.first = first; run.flops = mt.flops;
-    run.zero_bytes = (size_t)n_strips * 32 * sizeof(uint32_t);
+    run.zero_bytes = (size_t)(8 + n_strips) * 32 * sizeof(uint32_t);
 }
 
 void build_mega(m2f_plan& P, Arena& ar, bool real) {
@@ -947,11 +971,13 @@ void build_mega(m2f_plan& P, Arena& ar, bool real) {
     const bool fits = NT <= M2F_MEGA_MAX_NT && hf <= M2F_MEGA_LDS_WORK && hb <= M2F_MEGA_LDS_WORK;
     uint32_t* status = ar.alloc<uint32_t>(16);
     P.mega_status = status;
+    unsigned long long* prof = ar.alloc<unsigned long long>(2 * 64);     // diagnostic builds (-DM2F_MEGA_PROF) only
     const bool use = real && want && fits && P.prec == M2F_PREC_BF16;
     {
         MegaTables mt;
         mega_tables(P, P.fwd, 0, halves_fwd, halves_bwd, mt);
         mega_place(P, ar, use, mt, P.mfwd, 0, W, bwd_fast, halves_fwd, halves_bwd, status);
+        P.mfwd.args.prof = prof;
     }
     if (P.train) {
         // the longest tail of the backward list whose every op can run inside the kernel (the head - the input gradient of
@@ -974,8 +1000,10 @@ void build_mega(m2f_plan& P, Arena& ar, bool real) {
         MegaTables mt;
         mega_tables(P, P.bwd, first, halves_fwd, halves_bwd, mt);
         mega_place(P, ar, use && first < P.bwd.size(), mt, P.mbwd, first, W, bwd_fast, halves_fwd, halves_bwd, status + 4);
+        P.mbwd.args.prof = prof + 64;
     }
     if (real && status) (void)hipMemset(status, 0, 16 * sizeof(uint32_t));
+    if (real && prof) (void)hipMemset(prof, 0, 128 * sizeof(unsigned long long));
 }
 
 int build_plan(m2f_plan& P, char* ws_base) {
@@ -1244,7 +1272,7 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
 // One persistent launch in place of a launch list (mega.h): re-arm the strip counters, then the kernel.
 int run_mega(m2f_plan::MegaRun& run, int prof_kind, hipStream_t s) {
     if (g_prof) g_prof->begin(prof_kind, run.flops);
-    M2F_HIP(hipMemsetAsync(run.args.progress, 0, run.zero_bytes, s));
+    M2F_HIP(hipMemsetAsync(run.args.queue, 0, run.zero_bytes, s));
     M2F_HIP(m2f_launch_mega(run.args, run.nt, run.grid, s));
     if (g_prof) g_prof->end();
     return 0;
@@ -1380,6 +1408,14 @@ int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
                     "): item " + std::to_string(out8[w + 1]) + " waited on strip " + std::to_string(out8[w + 2]) + " at " +
                     std::to_string(out8[w + 3]));
     }
+    return 0;
+}
+
+/* diagnostic (-DM2F_MEGA_PROF builds): the persistent kernels' tick table, [2 runs][8 kinds][8 fields]; clears it */
+int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
+    if (!plan->mfwd.on || !plan->mfwd.args.prof) return fail("no persistent kernels in this plan");
+    M2F_HIP(hipMemcpy(out128, plan->mfwd.args.prof, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    M2F_HIP(hipMemset(plan->mfwd.args.prof, 0, 128 * sizeof(unsigned long long)));
     return 0;
 }
 

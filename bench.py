@@ -10,7 +10,13 @@ The headline metric (BASELINE.json) is utterances/s; per-GPU work is fixed (weak
 Workload = BASELINE.json configs[2] ("c3": shipped depth, roberta-large 1024 + wav2vec2 768, B=64 x L=16, bf16) - the largest
 single-GPU configuration and the one north_star's target is stated on; configs[1] ("c2") runs with --workload c2.
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel = the grouped MFMA GEMM,
-timed live with hipEvents per launch) and `cpu_baseline` (the CPU oracle on the host cores, N=1 only).
+timed live with hipEvents per launch; `roofline.fam_gemm` = the same figure over the fusion-attention stack's GEMM
+launches alone, the kernels north_star's target is stated on), `secondary` (the other single-GPU configuration, C2) and
+`cpu_baseline` (the CPU oracle on the host cores, N=1 only).
+
+`python bench.py --gpus N` started WITHOUT a torchrun environment launches its own N ranks (one child process per GPU
+through torch.distributed.run, decided before anything touches the GPU) and exits with their status; a rank whose RCCL
+world size differs from --gpus exits non-zero instead of measuring something else.
 """
 import argparse
 import json
@@ -110,6 +116,180 @@ def cpu_baseline(cfg, B, L, budget_s=20.0):
                       f"{sec * 1e3:.0f} ms/step, torch threads={threads}, os.cpu_count()={os.cpu_count()}"}
 
 
+
+def source_hash():
+    """sha256 over the kernel sources and headers: committed profile digests carry the hash they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "multimodal-emotion-recognition_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_profile_digest(kind, workload, dtype):
+    """profiles/<kind>_<workload>_<dtype>.json if present; `stale` when it was measured on other kernel sources."""
+    path = os.path.join(ROOT, "profiles", f"{kind}_{workload}_{dtype}.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    d["_source"] = os.path.relpath(path, ROOT)
+    d["_stale"] = d.get("source_hash") != source_hash()
+    return d
+
+
+LAUNCH_NAMES = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "dropout", "ce", "ln_reduce",
+                "cast_bf16", "persistent_fwd", "persistent_bwd"]
+PARTS = ["encoders", "fusion", "classifier"]
+
+
+def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump=""):
+    cfg, B, L = wl["cfg"], wl["B"], wl["L"]
+    torch.manual_seed(0)                               # identical replicas on every rank
+    model = M2FNet(cfg, precision=dtype).to(device).train()
+    opt = FusedAdam(model, lr=5e-5, weight_decay=0.01)
+    stepper = dp.DataParallelStep(model, opt, n_buckets=buckets, exchange=exchange)
+    text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device, ragged=ragged)
+    n_valid = int((~mask).sum().item())                # utterances of this rank's batch (= B*L unless --ragged)
+    eng = model.engine()
+    plan = eng.plan(B, L, True, True)
+
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        # inputs are resident in the plan's staging buffers before the timed region starts
+        plan.set_inputs(text, audio, mask, emotion)
+
+        def one_step():
+            plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
+            stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
+
+        eng.publish_grads()
+        for _ in range(max(warmup, 3)):                # >= 3: eager warm-up, graph capture, first replay
+            one_step()
+        side.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        side.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed = dp.reduce_metrics([elapsed], device=device)[0]
+        loss = float(stepper.reducer.global_loss().item())
+        plan.check_status()
+
+        # ---- secondary figure: forward + criterion + backward only (SURVEY 8-d's strict metric; `value` above also
+        # pays for the optimizer and, at N > 1, the gradient exchange) ---------------------------------------------
+        n_fb = max(10, min(steps, 50))
+        for _ in range(3):
+            plan.step(0.1, False, False, use_graph)
+        side.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(n_fb):
+            plan.step(0.1, False, False, use_graph)
+        side.synchronize()
+        fb_sec = (time.perf_counter() - tf0) / n_fb
+
+        # ---- roofline of the dominant kernel (grouped GEMM), per-launch hipEvent timing ------------------
+        for _ in range(5):
+            plan.step_timed(0.1, False, False)
+        reps = [plan.step_timed(0.1, False, False) for _ in range(10)]
+        ev_empty_ms, ev_trivial_ms = runtime.event_overhead(200)
+    n_l = len(reps[0])
+    avg_ms = [sum(r[i][1] for r in reps) / len(reps) for i in range(n_l)]
+    kinds = [reps[0][i][0] & 31 for i in range(n_l)]
+    parts = [reps[0][i][0] >> 5 for i in range(n_l)]
+    flops = [reps[0][i][2] for i in range(n_l)]
+    if dump:
+        with open(dump, "w") as f:
+            for i in range(n_l):
+                tf = flops[i] / (avg_ms[i] * 1e-3) / 1e12 if avg_ms[i] > 0 else 0.0
+                f.write(f"{i:4d} {LAUNCH_NAMES[kinds[i]]:14s} {PARTS[parts[i]]:10s} {avg_ms[i] * 1e3:9.2f} us {flops[i] / 1e9:9.3f} GFLOP {tf:8.1f} TFLOP/s\n")
+    # every launch that carries GEMM FLOPs: the grouped GEMM launches, or - when the persistent kernels are on - the two
+    # persistent launches (whose time then also holds the attention / LayerNorm items inside: conservative)
+    gemm_idx = [i for i in range(n_l) if kinds[i] in (0, 1, 2, 11, 12)]
+    gemm_ms = sum(avg_ms[i] for i in gemm_idx)
+    gemm_fl = sum(flops[i] for i in gemm_idx)
+    fam_idx = [i for i in gemm_idx if kinds[i] in (0, 1) and parts[i] == 1]
+    fam_ms, fam_fl = sum(avg_ms[i] for i in fam_idx), sum(flops[i] for i in fam_idx)
+    c = model.m2f_config
+    _, fb_per_slot = layout.flops_per_slot(c, L)
+    ms_per_step = elapsed / steps * 1e3
+    nv = torch.tensor([float(n_valid)], dtype=torch.float64, device=device)
+    if world > 1:                                      # SUM over ranks of the valid-utterance counts
+        torch.distributed.all_reduce(nv)
+    n_valid_all = int(nv.item())
+    utt_per_s = n_valid_all / (elapsed / steps)
+    slots_per_s = world * B * L / (elapsed / steps)          # padded slots are computed too
+    achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[dtype]
+    wl_key = [k for k, v in WORKLOADS.items() if v is wl][0]
+    # HBM-side bytes per GEMM launch and the kernels' own begin..end durations cannot be read from inside the process: they
+    # come from committed rocprofv3 passes of this same command (tools/traffic.sh, tools/kstats_bench.sh) - and are only
+    # quoted while the kernel sources are the ones they were measured on
+    traffic = load_profile_digest("traffic", wl_key, dtype)
+    kstats = load_profile_digest("kstats", wl_key, dtype)
+    rocprof = None
+    if kstats is not None:
+        rocprof = {"source": kstats["_source"], "stale": kstats["_stale"]}
+        if not kstats["_stale"]:
+            rocprof.update({"avg_launch_us": kstats["avg_launch_us"], "gemm_ms_per_step": kstats["gemm_ms_per_step"],
+                            "achieved": kstats.get("gemm_gflop_per_step", gemm_fl / 1e9) / kstats["gemm_ms_per_step"] / 1e3})
+    out = {
+        "metric": "utterances/sec (fwd+bwd) M2FNet fusion, MELD dialogues, 1/2/4/8 MI355X",
+        "value": utt_per_s, "unit": "utterances/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": wl["name"] + (" [MELD-like ragged lengths, valid utterances counted]" if ragged else ""),
+                   "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B, "valid_utterances": n_valid_all,
+                   "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
+                   "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({stepper.reducer.exchange})" if world > 1 else "") + " + fused Adam",
+                   "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
+                   "launches_per_step": plan.num_launches(), "persistent_kernels": plan.persistent(),
+                   "source_hash": source_hash()},
+        "loss": loss,
+        "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": n_valid / fb_sec, "steps": n_fb,
+                         "note": "fwd + CE + bwd graph replays on rank 0, optimizer and gradient exchange excluded"},
+        "step_tflops": slots_per_s * fb_per_slot / 1e12,
+        "step_frac_of_peak": slots_per_s * fb_per_slot / 1e12 / (peak * world),
+    }
+    if roofline:
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "m2f_gemm16_dense_kernel / m2f_gemm16_table_kernel (bf16) or m2f_gemm_kernel (fp32): grouped MFMA GEMM, forward / dgrad / wgrad launches of one step"
+                                       + (" [persistent kernels on: m2f_mega_kernel + m2f_gemm16_table_kernel]" if plan.persistent() else ""),
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": None if traffic is None or traffic["_stale"] else float(traffic["traffic_bytes_per_launch"]),
+            "traffic_source": None if traffic is None else {"file": traffic["_source"], "stale": traffic["_stale"]},
+            "launches_per_step": len(gemm_idx), "avg_launch_us": gemm_ms / max(len(gemm_idx), 1) * 1e3,
+            # the fusion-attention stack's own GEMM launches (q/v, k, out-projection, Linear(2E->E); forward + input gradient):
+            # north_star states its roofline target on these.  Their weight-gradient problems run inside the ONE table launch
+            # of the step and cannot be timed apart from the other layers'.
+            "fam_gemm": None if not fam_idx else {
+                "achieved": fam_fl / (fam_ms * 1e-3) / 1e12, "peak": peak, "frac": fam_fl / (fam_ms * 1e-3) / 1e12 / peak,
+                "launches": len(fam_idx), "gflop": fam_fl / 1e9, "ms": fam_ms, "avg_launch_us": fam_ms / len(fam_idx) * 1e3,
+                "what": "forward + input-gradient GEMM launches of the fusion stack (hipEvent intervals)"},
+            # what a hipEvent interval holds besides the kernel's own begin..end (which is what rocprofv3 reports):
+            # NOT subtracted from `achieved`, stated so the two can be reconciled
+            "event_interval_overhead_us": {"empty_pair": ev_empty_ms * 1e3, "pair_around_one_thread_kernel": ev_trivial_ms * 1e3},
+            "rocprof": rocprof,
+            "algorithmic_gflop_per_step": gemm_fl / 1e9, "gemm_ms_per_step": gemm_ms,
+            "all_kernels_ms_per_step_eager": sum(avg_ms),
+        }
+    del stepper, opt, model, plan, eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,160 +308,49 @@ def main():
     ap.add_argument("--grad-exchange", default="auto", choices=["auto", "fp32", "bf16"],
                     help="dtype of the gradient all-reduce at N > 1 (auto: bf16 for --dtype bf16, fp32 for --dtype fp32)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch timing table (kind, us, GFLOP) to this file")
+    ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
+                    help="second single-GPU configuration reported under `secondary` (N = 1 only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher environment: start the ranks ourselves - fresh child processes, before this process touches the GPU
+        import subprocess
+        port = int(os.environ.get("MASTER_PORT", "29533"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     rank, world, local = dp.init_distributed()
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
+        print(f"bench.py: the process group has {world} rank(s) but --gpus {args.gpus} was asked for; refusing to report a "
+              f"{args.gpus}-GPU number", file=sys.stderr)
+        sys.exit(3)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     runtime.require_gpu()
 
     wl = WORKLOADS[args.workload]
-    cfg, B, L = wl["cfg"], wl["B"], wl["L"]
-    torch.manual_seed(0)                               # identical replicas on every rank
-    model = M2FNet(cfg, precision=args.dtype).to(device).train()
-    opt = FusedAdam(model, lr=5e-5, weight_decay=0.01)
-    exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
-    stepper = dp.DataParallelStep(model, opt, n_buckets=args.buckets, exchange=exchange)
-    text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device, ragged=args.ragged)
-    n_valid = int((~mask).sum().item())                # utterances of this rank's batch (= B*L unless --ragged)
-    eng = model.engine()
-    plan = eng.plan(B, L, True, True)
     use_graph = not args.no_graph
-
-    side = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(side):
-        # inputs are resident in the plan's staging buffers before the timed region starts
-        plan.set_inputs(text, audio, mask, emotion)
-
-        def one_step():
-            plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
-            stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
-
-        eng.publish_grads()
-        for _ in range(max(args.warmup, 3)):           # >= 3: eager warm-up, graph capture, first replay
-            one_step()
-        side.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-        side.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        elapsed = time.perf_counter() - t0
-        elapsed = dp.reduce_metrics([elapsed], device=device)[0]
-        loss = float(stepper.reducer.global_loss().item())
-
-        # ---- secondary figure: forward + criterion + backward only (SURVEY 8-d's strict metric; `value` above also
-        # pays for the optimizer and, at N > 1, the gradient exchange) ---------------------------------------------
-        n_fb = max(10, min(args.steps, 50))
-        for _ in range(3):
-            plan.step(0.1, False, False, use_graph)
-        side.synchronize()
-        tf0 = time.perf_counter()
-        for _ in range(n_fb):
-            plan.step(0.1, False, False, use_graph)
-        side.synchronize()
-        fb_sec = (time.perf_counter() - tf0) / n_fb
-
-        # ---- roofline of the dominant kernel (grouped GEMM), per-launch hipEvent timing ------------------
-        rows = []
-        for _ in range(5):
-            rows = plan.step_timed(0.1, False, False)
-        reps = [plan.step_timed(0.1, False, False) for _ in range(10)]
-        ev_empty_ms, ev_trivial_ms = runtime.event_overhead(200)
-    n_l = len(reps[0])
-    avg_ms = [sum(r[i][1] for r in reps) / len(reps) for i in range(n_l)]
-    kinds = [reps[0][i][0] for i in range(n_l)]
-    flops = [reps[0][i][2] for i in range(n_l)]
-    if args.dump_launches and rank == 0:
-        names = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "dropout", "ce", "ln_reduce", "cast_bf16"]
-        with open(args.dump_launches, "w") as f:
-            for i in range(n_l):
-                tf = flops[i] / (avg_ms[i] * 1e-3) / 1e12 if avg_ms[i] > 0 else 0.0
-                f.write(f"{i:4d} {names[kinds[i]]:11s} {avg_ms[i] * 1e3:9.2f} us {flops[i] / 1e9:9.3f} GFLOP {tf:8.1f} TFLOP/s\n")
-    gemm_idx = [i for i in range(n_l) if kinds[i] in (0, 1, 2)]
-    gemm_ms = sum(avg_ms[i] for i in gemm_idx)
-    gemm_fl = sum(flops[i] for i in gemm_idx)
-    c = model.m2f_config
-    _, fb_per_slot = layout.flops_per_slot(c, L)
-    ms_per_step = elapsed / args.steps * 1e3
-    nv = torch.tensor([float(n_valid)], dtype=torch.float64, device=device)
-    if world > 1:                                      # SUM over ranks of the valid-utterance counts
-        torch.distributed.all_reduce(nv)
-    n_valid_all = int(nv.item())
-    utt_per_s = n_valid_all / (elapsed / args.steps)
-    slots_per_s = world * B * L / (elapsed / args.steps)          # padded slots are computed too
-    achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    peak = PEAK_TFLOPS[args.dtype]
-    # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process, so the figure comes from the
-    # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/traffic.sh), if present
-    traffic, traffic_src = None, None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"traffic_{args.workload}_{args.dtype}.json")
-    if os.path.exists(tf):
-        try:
-            with open(tf) as f:
-                traffic = float(json.load(f)["traffic_bytes_per_launch"])
-            traffic_src = os.path.relpath(tf, os.path.dirname(os.path.abspath(__file__)))
-        except (OSError, ValueError, KeyError):
-            traffic = None
-
-    rocprof = None
-    kf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"kstats_{args.workload}_{args.dtype}.json")
-    if os.path.exists(kf):                             # the kernels' own begin..end from the committed rocprofv3 --stats run
-        try:
-            with open(kf) as f:
-                k = json.load(f)
-            rocprof = {"avg_launch_us": k["avg_launch_us"], "gemm_ms_per_step": k["gemm_ms_per_step"],
-                       "achieved": gemm_fl / (k["gemm_ms_per_step"] * 1e-3) / 1e12,
-                       "source": os.path.relpath(kf, os.path.dirname(os.path.abspath(__file__)))}
-        except (OSError, ValueError, KeyError):
-            rocprof = None
-
+    exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
+    res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
+                       roofline=True, dump=args.dump_launches if rank == 0 else "")
     if rank == 0:
-        out = {
-            "metric": "utterances/sec (fwd+bwd) M2FNet fusion, MELD dialogues, 1/2/4/8 MI355X",
-            "value": utt_per_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl["name"] + (" [MELD-like ragged lengths, valid utterances counted]" if args.ragged else ""),
-                       "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B, "valid_utterances": n_valid_all,
-                       "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
-                       "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({stepper.reducer.exchange})" if world > 1 else "") + " + fused Adam",
-                       "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
-                       "launches_per_step": plan.num_launches()},
-            "loss": loss,
-            "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": n_valid / fb_sec, "steps": n_fb,
-                             "note": "fwd + CE + bwd graph replays on rank 0, optimizer and gradient exchange excluded"},
-            "step_tflops": slots_per_s * fb_per_slot / 1e12,
-            "step_frac_of_peak": slots_per_s * fb_per_slot / 1e12 / (peak * world),
-            "roofline": {
-                "bound": "mfma", "kernel": "m2f_gemm16_dense_kernel / m2f_gemm16_table_kernel (bf16) or m2f_gemm_kernel (fp32): grouped MFMA GEMM, forward / dgrad / wgrad launches of one step",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "launches_per_step": len(gemm_idx), "avg_launch_us": gemm_ms / max(len(gemm_idx), 1) * 1e3,
-                # what a hipEvent interval holds besides the kernel's own begin..end (which is what rocprofv3 reports):
-                # NOT subtracted from `achieved`, stated so the two can be reconciled
-                "event_interval_overhead_us": {"empty_pair": ev_empty_ms * 1e3, "pair_around_one_thread_kernel": ev_trivial_ms * 1e3},
-                "rocprof": rocprof,
-                "algorithmic_gflop_per_step": gemm_fl / 1e9, "gemm_ms_per_step": gemm_ms,
-                "all_kernels_ms_per_step_eager": sum(avg_ms),
-            },
-        }
+        out = res
+        if world == 1 and args.secondary != "none" and args.secondary != args.workload:
+            # the other single-GPU configuration of BASELINE.json, same protocol, shorter run
+            sec = run_workload(WORKLOADS[args.secondary], args.dtype, rank, world, device, max(20, args.steps // 2), args.warmup,
+                               use_graph, False, args.buckets, exchange, roofline=True, dump="")
+            out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "fwd_bwd_only", "step_tflops", "step_frac_of_peak")}
+            out["secondary"]["workload"] = sec["config"]["workload"]
+            out["secondary"]["roofline"] = {k: sec["roofline"][k] for k in ("achieved", "peak", "frac", "fam_gemm", "launches_per_step")}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 share = len(os.sched_getaffinity(0))
             except AttributeError:
                 share = os.cpu_count() or 1
             torch.set_num_threads(max(1, min(share, 16)))       # the GPU box gives one GPU a 16-core share
-            eval_cfg = dict(cfg, dropout=0.0)
-            out["cpu_baseline"] = cpu_baseline(eval_cfg, B, L, args.cpu_budget)
+            eval_cfg = dict(wl["cfg"], dropout=0.0)
+            out["cpu_baseline"] = cpu_baseline(eval_cfg, wl["B"], wl["L"], args.cpu_budget)
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

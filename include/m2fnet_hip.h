@@ -109,8 +109,9 @@ int m2f_gather_dialogues(const float* text_table, int d_text, const float* audio
 /* Measurement aid: one EAGER m2f_step with a hipEvent pair recorded on `stream` around every launch.  Fills, per
  * launch, kinds[] (0/1/2 = grouped GEMM forward/dgrad/wgrad form, 3/4 attention fwd/bwd, 5/6 LayerNorm fwd/bwd,
  * 7 dropout-mask, 8 criterion, 9 LayerNorm-parameter reduce, 10 bf16 cast / token-transpose copies, 11 / 12 the persistent
- * forward / backward-chain kernel - flops[] then holds the GEMM FLOPs of every op inside), ms[] (device time) and flops[]
- * (algorithmic FLOPs of the launch, 0 for row-wise kernels).  Synchronises the stream.  Returns the number of launches, or <0. */
+ * forward / backward-chain kernel - flops[] then holds the GEMM FLOPs of every op inside; chain launches carry + 32 x their
+ * part of the model: 0 modality encoders, 1 fusion stack (FusionAttentionModule, src/model.py:13-20), 2 classifier), ms[]
+ * (device time) and flops[] (algorithmic FLOPs of the launch, 0 for row-wise kernels).  Synchronises the stream.  Returns the number of launches, or <0. */
 int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream,
                    int max_entries, int* kinds, float* ms, double* flops);
 

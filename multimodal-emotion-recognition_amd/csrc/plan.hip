@@ -161,6 +161,7 @@ struct Op {
     std::vector<LnProblem> lp;
     float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;      // OP_DROPOUT
     std::vector<std::pair<int, int>> src;       // (chain id, index in that chain) of the ops merged into this one
+    int group = 0;                              // 0 modality encoders + projections, 1 fusion stack (reference src/model.py:13-20,129-131), 2 classifier
 };
 
 struct Launch {
@@ -171,6 +172,7 @@ struct Launch {
     LnBatch lb;
     float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;
     std::vector<std::pair<int, int>> src;
+    int group = 0;
 };
 
 struct Arena {
@@ -552,6 +554,8 @@ struct Builder {
             }
             P.bufs[M2F_BUF_FAM0_OUT] = fam.empty() ? nullptr : fam[0].t_out;
         }
+        for (Op& o : chain_f) o.group = 1;                  // everything so far = the fusion stack
+        const size_t cls_f0 = chain_f.size();
         // classifier (src/model.py:89-100,143): Linear0, [ReLU, Linear]*(n-2), ReLU, Dropout, Linear
         const int hid = c.cls_hidden, C = c.cls_out;
         const int hidp = pad8(hid);
@@ -585,6 +589,7 @@ struct Builder {
             g.bias = W(lp.b);
             chain_f.push_back(op_gemm(M2F_LAYOUT_NT, g));
         }
+        for (size_t i = cls_f0; i < chain_f.size(); ++i) chain_f[i].group = 2;
         float* dlogits = ar.f((size_t)T * C);
         P.bufs[M2F_BUF_DLOGITS] = dlogits;
         P.loss_terms = ar.f((size_t)T * 2);
@@ -640,6 +645,8 @@ struct Builder {
             }
             chain_b.push_back(o);
         }
+        for (Op& o : chain_b) o.group = 2;                  // classifier backward
+        const size_t fam_b0 = chain_b.size();
         // fusion layers, last to first.  `dz` = gradient w.r.t. the pre-ReLU output of layer i (the
         // ReLU/dropout gate was applied by the producer's epilogue).
         const float* dz = d_t;
@@ -694,6 +701,7 @@ struct Builder {
             dz = dt;
         }
         d_t = const_cast<float*>(dz);
+        for (size_t i = fam_b0; i < chain_b.size(); ++i) chain_b[i].group = 1;
         // gradient through the post-projection dropout (src/model.py:113,125)
         for (int bi = 0; bi < 2; ++bi) {
             float* dxp = bi == 0 ? d_a : d_t;
@@ -751,7 +759,7 @@ std::vector<Op> merge_chains(const std::vector<Op>& A, const std::vector<Op>& B)
 void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Launch>& out) {
     for (const Op& o : ops) {
         Launch l;
-        l.kind = o.kind; l.layout = o.layout; l.src = o.src;
+        l.kind = o.kind; l.layout = o.layout; l.src = o.src; l.group = o.group;
         memset(&l.gb, 0, sizeof(l.gb)); memset(&l.ab, 0, sizeof(l.ab)); memset(&l.lb, 0, sizeof(l.lb));
         switch (o.kind) {
             case OP_GEMM:
@@ -1236,6 +1244,7 @@ int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s, size_t fir
         hipError_t e = hipSuccess;
         if (g_prof) {
             int k = l.kind == OP_GEMM ? l.layout : (l.kind + 2);     // 0..2 gemm NT/NN/TN, 3 attn fwd, 4 attn bwd, 5 ln fwd, 6 ln bwd, 7 dropout
+            k += 32 * l.group;                                       // + 32 x (0 encoders, 1 fusion stack, 2 classifier)
             double f = l.kind == OP_GEMM ? gemm_flops(l.gb) : (l.kind == OP_ATTN_FWD ? attn_flops(l.ab, false) : (l.kind == OP_ATTN_BWD ? attn_flops(l.ab, true) : 0.0));
             g_prof->begin(k, f);
         }

@@ -399,6 +399,7 @@ template <bool G16>
 __global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, int64_t n4, float lr_bc1, float beta1, float beta2,
                                                        float eps, float wd, float inv_sqrt_bc2, const float* __restrict__ gs_ptr) {
+#pragma clang fp contract(fast)      // (this kernel has no twin in mega.hip to stay bit-identical with)
     const float gs = gs_ptr ? 1.0f / *gs_ptr : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 pp = reinterpret_cast<f32x4*>(p)[i];

@@ -10,10 +10,13 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = sum(int(r["Calls"]) for r in rows if "m2f_ce_kernel" in r["Name"])
-gemm = [r for r in rows if "m2f_gemm" in r["Name"]]
+gemm = [r for r in rows if "m2f_gemm" in r["Name"] or "m2f_mega" in r["Name"]]
 calls = sum(int(r["Calls"]) for r in gemm)
 total_ns = sum(float(r["TotalDurationNs"]) for r in gemm)
-out = {"steps_in_run": steps, "gemm_launches_per_step": calls / steps, "gemm_ms_per_step": total_ns / steps / 1e6,
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (source_hash: bench.py only quotes this digest while the kernel sources are the ones measured)
+out = {"source_hash": bench.source_hash(), "steps_in_run": steps, "gemm_launches_per_step": calls / steps, "gemm_ms_per_step": total_ns / steps / 1e6,
        "avg_launch_us": total_ns / calls / 1e3,
        "kernels": {r["Name"][:100]:
                    {"calls_per_step": int(r["Calls"]) / steps, "avg_us": float(r["AverageNs"]) / 1e3} for r in gemm},

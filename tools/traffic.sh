@@ -29,14 +29,16 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
 def avg(C, pred):
     v = sum(x[0] for k, x in per[C].items() if pred(k)); n = sum(x[1] for k, x in per[C].items() if pred(k))
     return (v / n if n else 0.0), n
-is_gemm = lambda k: "m2f_gemm" in k
+is_gemm = lambda k: "m2f_gemm" in k or "m2f_mega" in k
 is_adam = lambda k: "m2f_adam" in k
 adam_rd, n_ad = avg("FETCH_SIZE", is_adam); adam_wr, _ = avg("WRITE_SIZE", is_adam)
 known_rd, known_wr = 16.0 * n_params, 12.0 * n_params          # bytes (padding of the flat buffer ignored: <0.1 %)
 cal_rd = known_rd / adam_rd if adam_rd else None                # bytes per FETCH_SIZE count incl. the gfx950 1/2 factor
 cal_wr = known_wr / adam_wr if adam_wr else None
 g_rd, n_g = avg("FETCH_SIZE", is_gemm); g_wr, _ = avg("WRITE_SIZE", is_gemm)
-out = {"workload": bench["config"]["workload"], "dtype": bench["dtype"], "gemm_dispatches_counted": n_g,
+sys.path.insert(0, R)
+import bench as bench_py
+out = {"source_hash": bench_py.source_hash(), "workload": bench["config"]["workload"], "dtype": bench["dtype"], "gemm_dispatches_counted": n_g,
        "adam_dispatches_counted": n_ad,
        "raw_counter_per_launch": {"gemm_FETCH_SIZE": g_rd, "gemm_WRITE_SIZE": g_wr, "adam_FETCH_SIZE": adam_rd, "adam_WRITE_SIZE": adam_wr},
        "calibration_bytes_per_count": {"FETCH_SIZE": cal_rd, "WRITE_SIZE": cal_wr,

@@ -45,6 +45,10 @@ CASES = {
     "real_768_1layer": (_cfg(768, 768, 768, 8, 8, 8, 1, 1, 1), 6, 14, [14, 10, 3, 8, 1, 12], "real"),
     # audio_mel width (300) with a legal head count, shipped-depth slice kept shallow for size
     "c2_slice": (_cfg(300, 768, 768, 4, 8, 8, 2, 2, 2), 4, 16, [16, 16, 5, 11], "randn"),
+    # BASELINE.json configs[2] = C3 geometry (roberta-large 1024 + wav2vec2 768, 8 heads -> head dims 128 / 96), depth 2,
+    # at both dialogue lengths SURVEY 8-d names (16 and 24 utterances), ragged
+    "c3_slice_l16": (_cfg(768, 1024, 768, 8, 8, 8, 2, 2, 2), 8, 16, [16, 16, 9, 3, 12, 16, 1, 7], "randn"),
+    "c3_slice_l24": (_cfg(768, 1024, 768, 8, 8, 8, 2, 2, 2), 8, 24, [24, 17, 9, 24, 2, 13, 20, 5], "randn"),
 }
 FULL_GRAD_CASES = {k for k in CASES if k.startswith("tiny")}
 

@@ -153,7 +153,7 @@ def test_graph_replay_equals_eager():
         assert torch.equal(pe.grad, pg.grad)
 
 
-@pytest.mark.parametrize("name", ["c1", "real_768_1layer", "c2_slice", "tiny_ragged"])
+@pytest.mark.parametrize("name", ["c1", "real_768_1layer", "c2_slice", "c3_slice_l16", "c3_slice_l24", "tiny_ragged"])
 def test_bf16_mode_within_stated_tolerance(golden_dir, name):
     fx = _load(golden_dir, name)
     cfg, text, audio, key_pad, emotion = _inputs(name, fx)

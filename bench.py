@@ -308,6 +308,9 @@ def main():
     ap.add_argument("--grad-exchange", default="auto", choices=["auto", "fp32", "bf16"],
                     help="dtype of the gradient all-reduce at N > 1 (auto: bf16 for --dtype bf16, fp32 for --dtype fp32)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch timing table (kind, us, GFLOP) to this file")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="form the process group (gloo when there is no GPU), check its size against --gpus, print it, exit: "
+                         "the launch path without the measurement (tests/test_dp_cpu.py)")
     ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
                     help="second single-GPU configuration reported under `secondary` (N = 1 only)")
     args = ap.parse_args()
@@ -321,10 +324,18 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         sys.exit(subprocess.run(cmd, env=env).returncode)
     rank, world, local = dp.init_distributed()
+    if torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size()       # the communicator's size, not the environment's claim
     if world != args.gpus:
         print(f"bench.py: the process group has {world} rank(s) but --gpus {args.gpus} was asked for; refusing to report a "
               f"{args.gpus}-GPU number", file=sys.stderr)
         sys.exit(3)
+    if args.rendezvous_only:
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None}))
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     runtime.require_gpu()

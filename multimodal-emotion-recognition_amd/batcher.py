@@ -48,11 +48,19 @@ class DeviceDialogueBatcher:
 
     def gather(self, dialogue_ids: Sequence[int], plan: Optional["runtime.Plan"] = None):
         """Fill `plan`'s staging buffers (or fresh tensors) with the batch; returns the collate_fn dict."""
-        idx = self.slot_index(dialogue_ids).to(self.device, non_blocking=True)
+        idx = self.slot_index(dialogue_ids)
+        b_in, l_in = idx.shape
+        if plan is not None and (plan.B, plan.L) != (b_in, l_in):
+            # a bucketed plan (runtime.Plan.set_inputs): the batch sits in the top-left corner, every other slot is padding
+            assert plan.B >= b_in and plan.L >= l_in, "batch does not fit the plan"
+            full = torch.full((plan.B, plan.L), -1, dtype=torch.int32)
+            full[:b_in, :l_in] = idx
+            idx = full
+        idx = idx.to(self.device, non_blocking=True)
         B, L = idx.shape
         T = B * L
         if plan is not None:
-            assert (plan.B, plan.L) == (B, L)
+            plan.in_B, plan.in_L = b_in, l_in
             text, audio, kp, lab = plan.text_in, plan.audio_in, plan.keypad_in, plan.labels_in
         else:
             text = torch.empty(T, self.text.shape[1], device=self.device)
@@ -64,5 +72,10 @@ class DeviceDialogueBatcher:
             idx.data_ptr(), T, text.data_ptr(), text.stride(0), audio.data_ptr(), audio.stride(0), kp.data_ptr(),
             lab.data_ptr(), runtime.stream_ptr()), "m2f_gather_dialogues")
         self._keep = idx
+        if plan is not None and b_in < B:
+            kp.view(B, L)[b_in:, 0] = 0                # one live, unlabeled slot per filler dialogue (Plan.set_inputs)
+        if plan is not None:
+            return {"text": text, "audio": audio, "padding_mask": kp.view(B, L)[:b_in, :l_in].bool(),
+                    "emotion": lab.view(B, L)[:b_in, :l_in]}
         return {"text": text.view(B, L, -1) if plan is None else text, "audio": audio.view(B, L, -1) if plan is None else audio,
                 "padding_mask": kp.view(B, L).bool(), "emotion": lab.view(B, L)}

@@ -61,6 +61,43 @@ def shard_dialogues(n_dialogues: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_dialogues, world))
 
 
+class ShardedLoader:
+    """Every rank iterates the SAME global batches (same loader, same shuffle seed) and keeps its dialogues r, r+W, ... of
+    each: the global batch - and with it the optimisation trajectory - is what the single-process run of the reference
+    (src/train.py:26-33) would see.  A batch with fewer dialogues than ranks leaves some ranks an EMPTY shard (B = 0): the
+    step still has to be taken (DataParallelStep adds a zero contribution) or the other ranks would wait in the all-reduce."""
+
+    def __init__(self, loader, rank: int, world: int):
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            n = batch["padding_mask"].shape[0]
+            mine = shard_dialogues(n, self.rank, self.world)
+            if mine:
+                idx = torch.as_tensor(mine, device=batch["padding_mask"].device)
+                out = {k: v.index_select(0, idx) for k, v in batch.items()}
+                # drop the columns that are padding for every dialogue of the shard (the batch was padded to ITS longest)
+                keep = int((~out["padding_mask"]).sum(dim=1).max().item())
+                out = {k: v[:, :keep].contiguous() for k, v in out.items()}
+            else:
+                out = {k: v[:0] for k, v in batch.items()}
+            yield out
+
+
+def broadcast_from_rank0(values: Sequence[float], device=None) -> List[float]:
+    """Rank 0's values on every rank (validation metrics, so that early stopping takes the same decision everywhere)."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if t.device.type == "cpu" and dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+    return t.cpu().tolist()
+
+
 class GradReducer:
     """Sum-all-reduce of [flat gradients | den | num] in `n_buckets` contiguous chunks.
 
@@ -106,6 +143,10 @@ class GradReducer:
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def zero_contribution(self) -> None:
+        """This rank holds no dialogue of the global batch: gradients, denominator and numerator are all zero."""
+        self.buf.zero_()
 
     def all_reduce(self, async_op: bool = False) -> None:
         if not dist.is_initialized():
@@ -179,9 +220,17 @@ class DataParallelStep:
                  use_graph: bool = True) -> torch.Tensor:
         eng = self.model.engine()
         B, L = mask.shape
-        plan = eng.plan(B, L, True, self.model.training and self.model.m2f_config.dropout > 0.0)
         cur = torch.cuda.current_stream(eng.device)
         eng.stream.wait_stream(cur)
+        if B == 0:                                    # empty shard: contribute zeros, but take part in every collective
+            with torch.cuda.stream(eng.stream):
+                self.reducer.zero_contribution()
+                eng.publish_grads()
+                self.reducer.reduce_and_step(self.optimizer)
+                loss = self.reducer.global_loss()
+            cur.wait_stream(eng.stream)
+            return loss
+        plan = eng.plan(B, L, True, self.model.training and self.model.m2f_config.dropout > 0.0)
         with torch.cuda.stream(eng.stream):
             plan.set_inputs(text if self.model.text_enabled else None, audio if self.model.audio_enabled else None,
                             mask, emotion)

@@ -7,6 +7,7 @@ No ``nn.Transformer*`` / ``nn.MultiheadAttention`` / ``nn.Linear`` forward is ev
 """
 from __future__ import annotations
 
+import collections
 import copy
 import math
 import os
@@ -121,6 +122,8 @@ class _Anchor(torch.autograd.Function):
         if plan.version != ctx.version:
             raise RuntimeError("M2FNet: the activations of this forward were overwritten by a later forward of the "
                                "same (B, L) shape; call backward() before the next forward()")
+        if plan.dlogits.shape != plan._dlogits.shape:
+            plan._dlogits.zero_()                 # filler slots of a bucketed plan carry no gradient
         plan.dlogits.copy_(dlogits.reshape(plan.dlogits.shape))
         plan.backward()
         ctx.model._engine.publish_grads()
@@ -155,7 +158,10 @@ class _Engine:
         lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
         to_i32 = lambda u: u - (1 << 32) if u >= (1 << 31) else u
         self.rng = torch.tensor([to_i32(lo), to_i32(hi), 0, 0], dtype=torch.int32, device=device)
-        self.plans: Dict[Tuple, runtime.Plan] = {}
+        # plan cache: least-recently-used first; at most `max_plans` plans (workspaces + captured graphs) stay alive
+        self.plans: "collections.OrderedDict[Tuple, runtime.Plan]" = collections.OrderedDict()
+        self.max_plans = int(os.environ.get("M2F_MAX_PLANS", "6"))
+        self.shape_buckets = model.shape_buckets
         self.grad_views = None
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
         self.stream = torch.cuda.Stream(device=device)    # hipGraph capture is illegal on the default stream
@@ -170,7 +176,18 @@ class _Engine:
             self.grad_views = [self.flat_grad[o: o + n].view(s) for (_, o, n, s) in self.items]
         return self.flat_grad
 
+    @staticmethod
+    def bucket(B: int, L: int) -> Tuple[int, int]:
+        """Plan shape for a batch of B dialogues x L utterances: L rounded up to a multiple of 16 (the attention kernels'
+        tile; MELD batches have L anywhere in 1..33 -> three shapes), B to a power of two below 8 and a multiple of 8 above
+        (only the last, partial batch of an epoch differs from batch_size)."""
+        Lb = (L + 15) // 16 * 16
+        Bb = 1 << max(B - 1, 0).bit_length() if B <= 8 else (B + 7) // 8 * 8
+        return Bb, Lb
+
     def plan(self, B: int, L: int, want_backward: bool, dropout_active: bool) -> runtime.Plan:
+        if self.shape_buckets:
+            B, L = self.bucket(B, L)
         key = (B, L, want_backward, dropout_active, self.precision)
         pl = self.plans.get(key)
         if pl is None:
@@ -181,9 +198,24 @@ class _Engine:
             train = want_backward or dropout_active
             if train:
                 self.ensure_grad()
+            self._evict(max(self.max_plans, 1) - 1)
             pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng)
             self.plans[key] = pl
+        else:
+            self.plans.move_to_end(key)
+            self._evict(max(self.max_plans, 1))
         return pl
+
+    def _evict(self, keep: int) -> None:
+        """Drop least-recently-used plans until at most `keep` are left: frees their workspaces and captured graphs."""
+        while len(self.plans) > keep:
+            _, old = self.plans.popitem(last=False)
+            torch.cuda.synchronize(self.device)                        # nothing queued may still use them
+            old.close()
+
+    def plan_bytes(self) -> int:
+        """HBM held by the cached plans' workspaces."""
+        return sum(p.nbytes() for p in self.plans.values())
 
     def publish_grads(self) -> None:
         """Expose the flat gradient buffer as ``p.grad`` views.  Gradients are OVERWRITTEN each backward
@@ -204,9 +236,11 @@ class M2FNet(nn.Module):
     """Drop-in for reference ``src/model.py:23-145``: ``M2FNet(config.model)``; ``forward(text, audio, mask)``
     with text [B,L,d_t], audio [B,L,d_a] fp32 and mask bool [B,L] (True = pad) -> logits [B,L,output_size]."""
 
-    def __init__(self, config, precision: Optional[str] = None):
+    def __init__(self, config, precision: Optional[str] = None, shape_buckets: Optional[bool] = None):
         super().__init__()
         self.config = config
+        # round batch shapes up to a few plan shapes (see _Engine.bucket); M2F_SHAPE_BUCKETS=0 plans every shape exactly
+        self.shape_buckets = (os.environ.get("M2F_SHAPE_BUCKETS", "1") != "0") if shape_buckets is None else bool(shape_buckets)
         c = M2FConfig.from_model_config(config)           # raises the reference's two ValueErrors
         self.m2f_config = c
         self.audio_enabled, self.text_enabled, self.fam_enabled = c.audio_enabled, c.text_enabled, c.fam_enabled
@@ -299,7 +333,7 @@ class M2FNet(nn.Module):
         else:
             loss = body()
         eng.publish_grads()
-        return loss[0]
+        return loss[0].clone()          # (the buffer is overwritten by the next step)
 
     def flat_parameters(self) -> torch.Tensor:
         return self.engine().flat

@@ -202,7 +202,7 @@ class Plan:
         self.keypad_in = self._view(BUF_KEYPAD, (self.T,), torch.uint8)
         self.labels_in = self._view(BUF_LABELS, (self.T,), torch.int64)
         self.class_w = self._view(BUF_CLASSW, (16,), torch.float32)
-        self.logits = self._view(BUF_LOGITS, (B, L, C), torch.float32)
+        self._logits = self._view(BUF_LOGITS, (B, L, C), torch.float32)
         if train and grads is not None:
             # (loss, den, num) live in the tail of the flat gradient buffer (see include/m2fnet_hip.h)
             assert grads.numel() >= params.numel() + 4, "gradient buffer needs a 64-float tail"
@@ -210,10 +210,25 @@ class Plan:
             assert self.loss.data_ptr() == lib().m2f_plan_buffer(self.handle, BUF_LOSS)
         else:
             self.loss = self._view(BUF_LOSS, (4,), torch.float32)
-        self.dlogits = self._view(BUF_DLOGITS, (B, L, C), torch.float32)
-        self.fam0_out = (self._view(BUF_FAM0_OUT, (B, L, pad8(cfg.d_fam)), torch.float32)[..., : cfg.d_fam]
-                         if cfg.fam_enabled else None)
+        self._dlogits = self._view(BUF_DLOGITS, (B, L, C), torch.float32)
+        self._fam0_out = (self._view(BUF_FAM0_OUT, (B, L, pad8(cfg.d_fam)), torch.float32)[..., : cfg.d_fam]
+                          if cfg.fam_enabled else None)
+        # shape of the batch last handed to set_inputs: a plan may be larger than the batch it runs (shape buckets), the
+        # result views below are cut to the batch
+        self.in_B, self.in_L = B, L
         self.version = 0          # bumped by every forward; backward checks it still owns the activations
+
+    @property
+    def logits(self) -> torch.Tensor:
+        return self._logits[: self.in_B, : self.in_L]
+
+    @property
+    def dlogits(self) -> torch.Tensor:
+        return self._dlogits[: self.in_B, : self.in_L]
+
+    @property
+    def fam0_out(self) -> Optional[torch.Tensor]:
+        return None if self._fam0_out is None else self._fam0_out[: self.in_B, : self.in_L]
 
     def _view(self, which: int, shape, dtype) -> torch.Tensor:
         p = lib().m2f_plan_buffer(self.handle, which)
@@ -240,19 +255,50 @@ class Plan:
 
     def set_inputs(self, text: Optional[torch.Tensor], audio: Optional[torch.Tensor], key_pad: torch.Tensor,
                    labels: Optional[torch.Tensor] = None) -> None:
-        """Device-to-device copies of one batch into the plan's staging buffers (async on the stream)."""
+        """Device-to-device copies of one batch into the plan's staging buffers (async on the stream).
+
+        The batch may be SMALLER than the plan (b <= B dialogues of l <= L utterances: the engine rounds shapes up to a few
+        buckets so that the variable dialogue lengths of real data do not create a plan per length).  The extra slots are
+        padding in the reference's own sense - zero features, padding_mask = True, label -1 (src/utils.py:15-31) - and each
+        extra DIALOGUE keeps one unmasked, unlabeled slot (a fully masked dialogue would produce NaN logits in the reference
+        too): it flows through the forward, contributes exactly zero to the loss and to every gradient,
+        and its logits are cut off by the `logits` view.  Valid logits do not depend on padding (SURVEY 8-a fact i)."""
+        b, l = key_pad.shape if key_pad.dim() == 2 else (self.B, self.L)
+        if b > self.B or l > self.L:
+            raise HipError(f"batch {b} x {l} does not fit the plan {self.B} x {self.L}")
+        self.in_B, self.in_L = b, l
+        if (b, l) == (self.B, self.L):
+            if text is not None and self.cfg.text_enabled:
+                self.text_in.copy_(text.reshape(self.T, -1), non_blocking=True)
+            if audio is not None and self.cfg.audio_enabled:
+                self.audio_in.copy_(audio.reshape(self.T, -1), non_blocking=True)
+            self.keypad_in.copy_(key_pad.reshape(self.T), non_blocking=True)
+            if labels is not None:
+                self.labels_in.copy_(labels.reshape(self.T), non_blocking=True)
+            return
+        B, L = self.B, self.L
         if text is not None and self.cfg.text_enabled:
-            self.text_in.copy_(text.reshape(self.T, -1), non_blocking=True)
+            self.text_in.zero_()
+            self.text_in.view(B, L, -1)[:b, :l].copy_(text, non_blocking=True)
         if audio is not None and self.cfg.audio_enabled:
-            self.audio_in.copy_(audio.reshape(self.T, -1), non_blocking=True)
-        self.keypad_in.copy_(key_pad.reshape(self.T), non_blocking=True)
+            self.audio_in.zero_()
+            self.audio_in.view(B, L, -1)[:b, :l].copy_(audio, non_blocking=True)
+        kp = self.keypad_in.view(B, L)
+        kp.fill_(1)
+        kp[:b, :l].copy_(key_pad, non_blocking=True)
+        if b < B:
+            kp[b:, 0] = 0                           # one live (unlabeled) slot per filler dialogue
+        self.labels_in.fill_(-1)
         if labels is not None:
-            self.labels_in.copy_(labels.reshape(self.T), non_blocking=True)
+            self.labels_in.view(B, L)[:b, :l].copy_(labels, non_blocking=True)
 
     def forward(self) -> torch.Tensor:
         self.version += 1
         check(lib().m2f_forward(self.handle, stream_ptr()), "m2f_forward")
         return self.logits
+
+    def nbytes(self) -> int:
+        return self.workspace.numel()
 
     def loss_fwd(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True):
         check(lib().m2f_loss(self.handle, label_smoothing, int(use_class_weights), int(normalise), stream_ptr()),
@@ -280,11 +326,16 @@ class Plan:
             raise HipError("m2f_step_timed: " + lib().m2f_last_error().decode())
         return [(kinds[i], ms[i], fl[i]) for i in range(n)]
 
-    def __del__(self):
+    def close(self) -> None:
+        """Destroy the plan (captured graph, launch lists) and drop its workspace."""
         h = getattr(self, "handle", None)
         if h and _lib is not None:
             _lib.m2f_plan_destroy(h)
-            self.handle = None
+        self.handle = None
+        self.workspace = None
+
+    def __del__(self):
+        self.close()
 
 
 def event_overhead(pairs: int = 200):

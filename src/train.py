@@ -19,6 +19,7 @@ from dataset import Dataset, DeviceLoader, collate_fn  # noqa: E402
 from metrics import BatchScores, move_batch  # noqa: E402
 from model import M2FNet  # noqa: E402
 from utils import get_config  # noqa: E402
+from mer_amd import dp  # noqa: E402
 from mer_amd.optim import FusedAdam, M2FCrossEntropyLoss  # noqa: E402
 
 try:
@@ -88,29 +89,51 @@ def write_checkpoint(path, epoch, model, optimizer):
 
 def main(config=None):
     config = get_config()
-    device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
-    print(f"Using device {device}...")
-    torch.manual_seed(int(_runtime(config, "seed", 0)))
+    # One process per GPU when launched under torchrun (WORLD_SIZE > 1) or with runtime.data_parallel: True - dialogues of every
+    # global batch are sharded over the ranks, gradients are summed over RCCL with the GLOBAL valid-utterance denominator
+    # (mer_amd/dp.py).  The reference is single-process (src/train.py:20); a single rank behaves exactly like it.
+    want_dp = _runtime(config, "data_parallel", "auto")
+    rank, world, local = dp.init_distributed() if want_dp in (True, "auto") else (0, 1, 0)
+    device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
+    if rank == 0:
+        print(f"Using device {device}..." + (f" ({world} ranks)" if world > 1 else ""))
+    torch.manual_seed(int(_runtime(config, "seed", 0)))       # identical replicas and identical shuffles on every rank
 
     train_set, val_set = Dataset(mode="train"), Dataset(mode="val")
     if _runtime(config, "device_batcher", False):          # embedding tables in HBM, one gather kernel per batch
         dl_train = DeviceLoader(train_set, device=device, seed=_runtime(config, "seed", 0), **config.train.data_loader)
         dl_val = DeviceLoader(val_set, device=device, **config.val.data_loader)
     else:
-        dl_train = torch.utils.data.DataLoader(train_set, collate_fn=collate_fn, **config.train.data_loader)
+        gen = torch.Generator().manual_seed(int(_runtime(config, "seed", 0)))
+        dl_train = torch.utils.data.DataLoader(train_set, collate_fn=collate_fn, generator=gen, **config.train.data_loader)
         dl_val = torch.utils.data.DataLoader(val_set, collate_fn=collate_fn, **config.val.data_loader)
+    if world > 1:
+        dl_train = dp.ShardedLoader(dl_train, rank, world)
 
     model = M2FNet(config.model, precision=_runtime(config, "precision", "fp32")).to(device)
+    # how train() runs the loop body: (fused m2f_step instead of forward / criterion / backward, as one hipGraph)
+    model.step_mode = (bool(_runtime(config, "fused_step", True)), bool(_runtime(config, "use_graph", True)))
     criterion = build_criterion(config.solver, train_set, device)
     optimizer = FusedAdam(model, lr=config.solver.lr, weight_decay=config.solver.weight_decay)
-    if config.wandb.enabled:
+    if world > 1:
+        model.dp_step = dp.DataParallelStep(model, optimizer, n_buckets=int(_runtime(config, "grad_buckets", 4)),
+                                            exchange=_runtime(config, "grad_exchange", "fp32"))
+    if config.wandb.enabled and rank == 0:
         start_wandb(config)
     lr_scheduler = build_scheduler(config.solver, optimizer)
     first_epoch = resume_if_requested(config, model, optimizer, device)
 
-    print("Training...")
+    if rank == 0:
+        print("Training...")
     training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, first_epoch, config, device)
-    print("Training complete")
+    if rank == 0:
+        print("Training complete")
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def _rank():
+    return torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
 
 
 # ---- early stopping on the validation LOSS with the reference's best-weights file protocol --------------------------
@@ -129,12 +152,14 @@ class EarlyStopper:
             return False
         if val_loss < self.best_loss:
             self.best_loss, self.epochs_without_improvement = val_loss, 0
-            if self.restore:
+            if self.restore and _rank() == 0:
                 write_checkpoint(self.best_path, epoch, model, optimizer)
             return False
         self.epochs_without_improvement += 1
         if self.epochs_without_improvement < self.patience:
             return False
+        if _rank() != 0:
+            return True
         print(f"Early stopping: patience {self.patience} reached")
         if self.restore:                                 # the final checkpoint becomes the best one; the side file goes away
             best = torch.load(self.best_path)
@@ -146,7 +171,8 @@ class EarlyStopper:
 
 def training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, start_epoch, config, device):
     solver = config.solver
-    log_to_wandb = config.wandb.enabled
+    rank0 = _rank() == 0
+    log_to_wandb = config.wandb.enabled and rank0
     save_path = os.path.abspath(config.checkpoint.save_path)
     os.makedirs(os.path.dirname(save_path), exist_ok=True)
     if log_to_wandb and config.wandb.watch_model:
@@ -160,13 +186,14 @@ def training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, s
         history["loss_values"].append(train_loss)
         history["val_loss_values"].append(val_loss)
 
-        if config.checkpoint.save_checkpoint:
+        if config.checkpoint.save_checkpoint and rank0:
             write_checkpoint(save_path, epoch, model, optimizer)
         lr_now = optimizer.param_groups[0]["lr"]
         if lr_scheduler is not None and solver.scheduler.enabled:
             lr_scheduler.step()
-        print(f"Epoch: {epoch} lr: {lr_now:.3E} Train=[{train_loss:.3E}] Val=[{val_loss:.3E}] "
-              f"Accuracy=[{accuracy * 100:.3f}%] Weighted_F1=[{weighted_f1 * 100:.3f}%]")
+        if rank0:
+            print(f"Epoch: {epoch} lr: {lr_now:.3E} Train=[{train_loss:.3E}] Val=[{val_loss:.3E}] "
+                  f"Accuracy=[{accuracy * 100:.3f}%] Weighted_F1=[{weighted_f1 * 100:.3f}%]")
         if log_to_wandb:
             wandb.log({"Params/Epoch": epoch, "Params/Learning_Rate": lr_now, "Train/Loss": train_loss,
                        "Validation/Loss": val_loss, "Validation/Accuracy": accuracy, "Validation/Weighted_F1": weighted_f1})
@@ -178,30 +205,34 @@ def training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, s
 
 
 def _step_mode(model, criterion):
-    """(fused, use_graph): the whole loop body as one m2f_step launch when the model / criterion are the HIP-backed ones."""
-    have_cfg = os.path.exists("./src/config.yaml")
-    cfg = get_config() if have_cfg else {}
-    fused = (bool(_runtime(cfg, "fused_step", True)) and isinstance(criterion, M2FCrossEntropyLoss)
-             and hasattr(model, "train_step"))
-    return fused, (bool(_runtime(cfg, "use_graph", True)) if have_cfg else True)
+    """(fused, use_graph): the whole loop body as one m2f_step launch when the model / criterion are the HIP-backed ones.
+    The two switches are read from the `runtime:` block ONCE, in main(), and travel on the model (`model.step_mode`)."""
+    fused, use_graph = getattr(model, "step_mode", (True, True))
+    return fused and isinstance(criterion, M2FCrossEntropyLoss) and hasattr(model, "train_step"), use_graph
 
 
 def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
     """One epoch; returns the mean of the per-batch losses (reference src/train.py:217-243)."""
     model.train()
     fused, use_graph = _step_mode(model, criterion)
+    dp_step = getattr(model, "dp_step", None)             # set by main() when there is more than one rank
     running = 0.0
-    progress = tqdm(enumerate(dl_train), total=len(dl_train), desc=f"Epoch {epoch}")
+    progress = tqdm(enumerate(dl_train), total=len(dl_train), desc=f"Epoch {epoch}", disable=_rank() != 0)
     for step, batch in progress:
         text, audio, emotion, padding_mask = move_batch(batch, device, non_blocking=True)
-        optimizer.zero_grad()
-        if fused:
-            loss = model.train_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
-                                    class_weights=criterion.weight, use_graph=use_graph)
+        if dp_step is not None:
+            # sharded step: local sum-gradient -> RCCL all-reduce with the global denominator -> fused Adam, all inside
+            loss = dp_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
+                           class_weights=criterion.weight, use_graph=use_graph)
         else:
-            loss = criterion(model(text, audio, padding_mask).permute(0, 2, 1), emotion)
-            loss.backward()
-        optimizer.step()
+            optimizer.zero_grad()
+            if fused:
+                loss = model.train_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
+                                        class_weights=criterion.weight, use_graph=use_graph)
+            else:
+                loss = criterion(model(text, audio, padding_mask).permute(0, 2, 1), emotion)
+                loss.backward()
+            optimizer.step()
         running += loss.item()
         if wandb_log:
             wandb.log({"Train/Running_loss": running / (step + 1), "Params/Global_step": epoch * len(dl_train) + step})
@@ -209,7 +240,11 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
 
 
 def validate(model, dl_val, criterion, device):
-    """-> (mean batch loss, accuracy, weighted_f1); scores by the per-batch rule of ``metrics.BatchScores``."""
+    """-> (mean batch loss, accuracy, weighted_f1); scores by the per-batch rule of ``metrics.BatchScores``.
+    With several ranks the replicas are identical: rank 0 evaluates the whole split (the mean-of-batches rule needs the
+    reference's batches, src/train.py:245-272) and every rank receives its three numbers."""
+    if _rank() != 0:
+        return tuple(dp.broadcast_from_rank0([0.0, 0.0, 0.0], device=device))
     model.eval()
     scores, loss_total = BatchScores(), 0.0
     with torch.inference_mode():
@@ -219,7 +254,7 @@ def validate(model, dl_val, criterion, device):
             loss_total += criterion(logits.permute(0, 2, 1), emotion).item()
             scores.update(logits, emotion)
     accuracy, weighted_f1 = scores.result()
-    return loss_total / len(dl_val), accuracy, weighted_f1
+    return tuple(dp.broadcast_from_rank0([loss_total / len(dl_val), accuracy, weighted_f1], device=device))
 
 
 if __name__ == "__main__":

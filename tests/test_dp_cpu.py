@@ -128,3 +128,60 @@ def test_reducer_buckets_cover_buffer():
         red = dp.GradReducer(buf, 10_000, n_buckets=nb)
         assert red.chunks[0][0] == 0 and red.chunks[-1][1] == buf.numel()
         assert all(a[1] == b[0] for a, b in zip(red.chunks[:-1], red.chunks[1:]))
+
+
+def test_bench_starts_its_own_ranks_and_refuses_a_wrong_world_size():
+    """`python bench.py --gpus 2` without a launcher environment must start two ranks itself (torch.distributed.run children)
+    and form a 2-rank group; a launcher environment whose world size disagrees with --gpus must exit non-zero."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(29900 + os.getpid() % 90)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"rendezvous": 2, "backend": "gloo"}
+    bad = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=bad,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_sharded_loader_partitions_every_batch_and_yields_empty_shards():
+    import mer_amd  # noqa: F401
+    from mer_amd import dp
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for B, L in ((5, 7), (2, 4), (1, 3)):
+        emo = torch.randint(0, 7, (B, L), generator=g)
+        for b in range(B):
+            emo[b, int(torch.randint(1, L + 1, (1,), generator=g)):] = -1
+        emo[0, :] = emo[0, :].clamp_min(0)              # the batch's longest dialogue is full length
+        batches.append({"text": torch.randn(B, L, 6, generator=g), "audio": torch.randn(B, L, 4, generator=g),
+                        "emotion": emo, "padding_mask": emo == -1})
+    world = 3
+    shards = [list(dp.ShardedLoader(batches, r, world)) for r in range(world)]
+    assert all(len(s) == len(batches) for s in shards)
+    for i, full in enumerate(batches):
+        B = full["emotion"].shape[0]
+        seen = 0
+        for r in range(world):
+            sh = shards[r][i]
+            mine = dp.shard_dialogues(B, r, world)
+            assert sh["emotion"].shape[0] == len(mine)
+            if not mine:
+                assert sh["text"].shape[0] == 0 and sh["padding_mask"].shape[0] == 0        # empty shard, still yielded
+                continue
+            Ls = sh["emotion"].shape[1]
+            assert torch.equal(sh["emotion"], full["emotion"][mine][:, :Ls])
+            assert torch.equal(sh["text"], full["text"][mine][:, :Ls]) and torch.equal(sh["audio"], full["audio"][mine][:, :Ls])
+            assert (full["emotion"][mine][:, Ls:] == -1).all(), "only all-padding columns may be dropped"
+            assert (~sh["padding_mask"]).any(dim=0).all() or Ls == 1
+            seen += int((sh["emotion"] != -1).sum())
+        assert seen == int((full["emotion"] != -1).sum())
+    # a rank with an empty shard contributes exact zeros to the exchange
+    buf = torch.randn(100 + dp.TAIL)
+    red = dp.GradReducer(buf, 100)
+    red.zero_contribution()
+    assert float(buf.abs().sum()) == 0.0 and float(red.global_den) == 0.0

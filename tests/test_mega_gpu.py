@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def _model(cfg, sd, mega, precision="bf16"):
     from mer_amd.model import M2FNet
-    m = M2FNet(cfg, precision=precision)
+    m = M2FNet(cfg, precision=precision, shape_buckets=False)      # exact shapes: partial strips / odd T are the point here
     m.load_state_dict(sd)
     m = m.to("cuda:0").train()
     m._want_mega = mega

@@ -116,3 +116,47 @@ def test_collate_fn_contract_matches_oracle():
     for k in ("text", "audio", "padding_mask", "emotion"):
         assert torch.equal(a[k], b[k]), k
     assert a["emotion"].dtype == torch.int64 and a["padding_mask"].dtype == torch.bool
+
+
+def test_plan_cache_is_bounded_over_real_dialogue_lengths():
+    """MELD batches have their longest dialogue anywhere in 1..33 plus a partial last batch: the engine rounds shapes up
+    to buckets (L to multiples of 16, B to 1/2/4/8/16/24/...), so L in 3..33 needs three train plans, the plan cache is
+    an LRU of at most `max_plans`, and the bucketed run computes exactly what the exact-shape run computes."""
+    from mer_amd.model import M2FNet
+    cfg = synth._cfg(40, 48, 64, 4, 4, 4, 1, 1, 1)
+    sd = synth.make_state_dict(cfg)
+    m = M2FNet(cfg)                                         # shape buckets on (default)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0").train()
+    exact = M2FNet(cfg, shape_buckets=False)
+    exact.load_state_dict(sd)
+    exact = exact.to("cuda:0").train()
+    g = torch.Generator().manual_seed(0)
+    for L in list(range(3, 34, 3)) + [33, 16, 17]:
+        B = int(torch.randint(3, 9, (1,), generator=g))
+        lengths = [int(x) for x in torch.randint(1, L + 1, (B,), generator=g)]
+        lengths[0] = L
+        batch = [t.cuda() for t in synth.make_inputs(cfg, B, L, lengths, "randn", seed=L)]
+        loss = m.train_step(*batch, use_graph=True)
+        if L in (3, 17, 33):                                # bucketed == exact, bit for bit (the filler slots add exact zeros)
+            ref = exact.train_step(*batch, use_graph=False)
+            eng, eng_x = m.engine(), exact.engine()
+            plan = eng.plans[next(reversed(eng.plans))]
+            plan_x = eng_x.plans[next(reversed(eng_x.plans))]
+            valid = ~batch[2]
+            assert plan.logits.shape == plan_x.logits.shape == (B, L, 7)
+            assert torch.equal(plan.logits[valid], plan_x.logits[valid])
+            assert abs(loss.item() - ref.item()) < 1e-6
+            assert (eng.flat_grad - eng_x.flat_grad).abs().max().item() <= 1e-6 * eng_x.flat_grad.abs().max().item()
+    eng = m.engine()
+    shapes = sorted({(k[0], k[1]) for k in eng.plans})
+    assert len(eng.plans) <= 6 and {s[1] for s in shapes} <= {16, 32, 48}, shapes
+    assert len({s[1] for s in shapes}) <= 3
+    assert eng.plan_bytes() <= eng.max_plans * max(p.nbytes() for p in eng.plans.values())
+    # LRU: with room for two plans only, the oldest goes
+    eng.max_plans = 2
+    for L in (5, 20, 40, 5):
+        batch = [t.cuda() for t in synth.make_inputs(cfg, 4, L, None, "randn", seed=L)]
+        m.train_step(*batch, use_graph=True)
+        assert len(eng.plans) <= 2
+    torch.cuda.synchronize()

@@ -193,3 +193,43 @@ def test_spill_guard_of_the_gemm_build(tmp_path):
     bad = remarks([(nt, 204), (tn, 0)])
     assert bad.returncode == 1 and "spills 204 VGPRs" in bad.stderr
     assert remarks([(tn, 0)]).returncode != 0          # no kernel of the guarded form found: the remark format changed
+
+
+def test_asm_load_checker_flags_a_copy_of_a_register_in_flight():
+    """csrc/check_asm_loads.py (run by the Makefile on gemm.hip's ISA): a register that an inline-asm load is still filling
+    must not be read, copied or overwritten before the hand-written wait - the pattern that corrupted a build in round 2."""
+    import importlib.util
+    path = os.path.join(ROOT, "multimodal-emotion-recognition_amd", "csrc", "check_asm_loads.py")
+    spec = importlib.util.spec_from_file_location("check_asm_loads", path)
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    good = """kern_good:
+	v_sub_u32_e32 v3, v166, v2
+	;;#ASMSTART
+	global_load_dwordx4 v[70:73], v3, s[18:19]
+	;;#ASMEND
+	v_sub_u32_e32 v3, v168, v2
+	;;#ASMSTART
+	global_load_dwordx4 v[74:77], v3, s[18:19] sc1
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(4)
+	;;#ASMEND
+	ds_write_b128 v9, v[70:73]
+	s_endpgm
+"""
+    bad = good.replace("kern_good", "kern_bad").replace("\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)",
+                                                        "\tv_mov_b64_e32 v[30:31], v[74:75]\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)")
+    other_block = good.replace("kern_good", "kern_branch").replace("\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)",
+                                                                   "\ts_branch .LBB0_9\n.LBB0_3:\n\tv_add_u32_e32 v70, 1, v70\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)")
+    note = good.replace("kern_good", "kern_note").replace("\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)",
+                                                          "\tv_readfirstlane_b32 s35, v70\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)")
+    res = {name: chk.scan(body, name) for name, body in chk.kernels(good + bad + other_block + note)}
+    assert set(res) == {"kern_good", "kern_bad", "kern_branch", "kern_note"}
+    assert res["kern_good"] == ([], [], True)
+    assert len(res["kern_bad"][0]) == 1 and "v_mov_b64" in res["kern_bad"][0][0]
+    assert res["kern_branch"][0] == [], "text behind an unconditional branch is another basic block"
+    assert res["kern_note"][0] == [] and len(res["kern_note"][1]) == 1
+    report = os.path.join(ROOT, "multimodal-emotion-recognition_amd", "csrc", "gemm.asmcheck")
+    if os.path.exists(report):                      # written by the build: the shipped kernels must be clean
+        assert not [l for l in open(report) if "ERROR" in l]

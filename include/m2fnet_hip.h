@@ -174,6 +174,11 @@ int m2f_gemm_fp8(int M, int N, int K, const uint8_t* a8, int lda, const uint8_t*
 int m2f_quantize_fp8(const float* src, uint8_t* dst, int64_t n, float scale, m2f_stream_t stream);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels the plan launches) ---------- */
+/* Number of bf16 GEMM launches this process has issued in the RING form (csrc/gemm.hip, m2f_gemm16_ring_kernel: LDS-direct
+ * operand ring, 128x128 tiles; taken by k-contiguous launches of at least M2F_RING_MIN = 200 such tiles unless M2F_RING=0).
+ * Diagnostic: lets a test assert that the form it means to check actually ran. */
+long long m2f_gemm_ring_launches(void);
+
 /* C[M,N] = epilogue(A x B); layout 0: C = A[M,K] B[N,K]^T (nn.Linear forward), 1: C = A[M,K] B[K,N]
  * (input gradient), 2: C = A[K,M]^T B[K,N] (weight gradient; bias_grad[M] = column sums of A).
  * Optional second operand segment (a1/b1, k1) = never-materialised torch.cat along the reduction dim. */

@@ -1196,6 +1196,13 @@ __global__ __launch_bounds__(M2F_MEGA_THREADS) void m2f_mega_kernel(const MegaAr
 
 }  // namespace
 
+// Re-arms the ticket and strip counters of a run.  A kernel, not a hipMemsetAsync: inside a captured graph the memset node
+// was observed not to take effect on replay when a second engine's graph ran in between (the persistent kernel then found
+// its queues exhausted and returned at once, leaving the previous step's outputs) - a kernel node has no such problem.
+__global__ void m2f_mega_rearm_kernel(unsigned* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
 hipError_t m2f_launch_mega(const MegaArgs& a, int nt, int grid, hipStream_t stream) {
     // NT = 3, 4 (dialogues of more than 32 utterances) are not instantiated: the five-slab attention backward spills
     // VGPRs at 256, and a spill is not allowed next to the inline-asm staging loads (check_spills.py); such plans keep
@@ -1208,6 +1215,7 @@ hipError_t m2f_launch_mega(const MegaArgs& a, int nt, int grid, hipStream_t stre
         if (e != hipSuccess) return e;
         attr_set[nt] = true;
     }
+    hipLaunchKernelGGL(m2f_mega_rearm_kernel, dim3(1), dim3(256), 0, stream, a.queue, (8 + a.n_strips) * 32);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(M2F_MEGA_THREADS), M2F_MEGA_LDS, stream, a);
     return hipGetLastError();
 }

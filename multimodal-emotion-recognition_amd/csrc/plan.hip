@@ -1278,10 +1278,9 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
     return 0;
 }
 
-// One persistent launch in place of a launch list (mega.h): re-arm the strip counters, then the kernel.
+// One persistent launch in place of a launch list (mega.h): m2f_launch_mega re-arms the counters, then runs the kernel.
 int run_mega(m2f_plan::MegaRun& run, int prof_kind, hipStream_t s) {
     if (g_prof) g_prof->begin(prof_kind, run.flops);
-    M2F_HIP(hipMemsetAsync(run.args.queue, 0, run.zero_bytes, s));
     M2F_HIP(m2f_launch_mega(run.args, run.nt, run.grid, s));
     if (g_prof) g_prof->end();
     return 0;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
     "m2f_plan_num_launches": (c_int, [c_void_p, c_int]),
     "m2f_plan_persistent": (c_int, [c_void_p]),
+    "m2f_gemm_ring_launches": (ctypes.c_longlong, []),
     "m2f_plan_status": (c_int, [c_void_p, ctypes.POINTER(c_uint32)]),
     "m2f_forward": (c_int, [c_void_p, c_void_p]),
     "m2f_loss": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),

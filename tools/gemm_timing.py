@@ -17,5 +17,5 @@ fn.restype = ctypes.c_int
 assert fn(buf) == 0
 c = list(buf)
 t0 = min(c[0], c[16])
-print("consumer: start %.2f | at B0 %.2f | B0 passed %.2f | k-loop done %.2f | epilogue done %.2f  (us)" % tuple((c[i] - t0) / 100.0 for i in range(5)))
+print("consumer: start %.2f | at B0 %.2f | B0 passed %.2f | k-loop done %.2f | epilogue done %.2f | ep: blk0 in regs %.2f | blk0 stored %.2f | blk1 in regs %.2f (x100 cycles)" % tuple((c[i] - t0) / 100.0 for i in range(8)))
 print("producer: start %.2f | setup done %.2f | D stages issued %.2f | stage0 stored %.2f | B0+issue %.2f | k-loop done %.2f  (us)" % tuple((c[16 + i] - t0) / 100.0 for i in range(6)))

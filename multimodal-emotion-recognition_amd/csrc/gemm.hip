@@ -1165,7 +1165,7 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
     return E;
 }
 
-template <int MI, int NI, int BM, int BN>
+template <int MI, int NI, int BM, int BN, bool PLAIN = false>      // PLAIN: the launch form has no optional terms (weight-gradient table)
 __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi& E, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn, char* ep) {
     const int M = E.M, N = E.N;
@@ -1269,8 +1269,9 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                 if (b == 0) { M2F_TS(6); }
             }
         };
-        const int fmask = (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0);
-        switch (fmask) {
+        const int fmask = PLAIN ? 0 : (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0);
+        if constexpr (PLAIN) blocks(std::integral_constant<int, 0>{});
+        else switch (fmask) {
 #define M2F_RING_EP(F) case F: blocks(std::integral_constant<int, F>{}); break;
             M2F_RING_EP(0) M2F_RING_EP(1) M2F_RING_EP(2) M2F_RING_EP(3) M2F_RING_EP(4) M2F_RING_EP(5) M2F_RING_EP(6) M2F_RING_EP(7)
             M2F_RING_EP(8) M2F_RING_EP(9) M2F_RING_EP(10) M2F_RING_EP(11) M2F_RING_EP(12) M2F_RING_EP(13) M2F_RING_EP(14) M2F_RING_EP(15)
@@ -1343,14 +1344,42 @@ __device__ __forceinline__ int ring_problem_of(const GemmBatch& gb, int bpos) {
     return pi;
 }
 
+// The fields both roles need of the problem a tile belongs to.  Grouped launches: the compact header in the kernel arguments.
+// TABLE form (the weight-gradient launch, ~100 problems): tile -> problem through gb.tile_prob, the problem from the device
+// table; the index is made provably uniform so that these are scalar loads.
+struct RingDesc {
+    const uint16_t* aq[2]; const uint16_t* bq[2];
+    int M, N, k[2], ldaq[2], ldbq[2], tile_begin, pi;
+    uint32_t flags;
+};
+template <bool TABLE>
+__device__ __forceinline__ RingDesc ring_desc(const GemmBatch& gb, int bpos) {
+    RingDesc D;
+    if constexpr (TABLE) {
+        D.pi = __builtin_amdgcn_readfirstlane((int)gb.tile_prob[bpos]);
+        const GemmProblem& P = gb.table[D.pi];
+        D.aq[0] = P.a.q[0]; D.aq[1] = P.a.q[0]; D.bq[0] = P.b.q[0]; D.bq[1] = P.b.q[0];
+        D.M = P.M; D.N = P.N; D.k[0] = P.a.k[0]; D.k[1] = 0;
+        D.ldaq[0] = P.a.ldq[0]; D.ldaq[1] = P.a.ldq[0]; D.ldbq[0] = P.b.ldq[0]; D.ldbq[1] = P.b.ldq[0];
+        D.tile_begin = P.tile_begin; D.flags = 0;                   // table problems carry no operand / epilogue options
+    } else {
+        D.pi = ring_problem_of(gb, bpos);
+        const GemmHot& H = gb.hot[D.pi];
+        D.aq[0] = H.aq[0]; D.aq[1] = H.aq[1]; D.bq[0] = H.bq[0]; D.bq[1] = H.bq[1];
+        D.M = H.M; D.N = H.N; D.k[0] = H.k[0]; D.k[1] = H.k[1];
+        D.ldaq[0] = H.ldaq[0]; D.ldaq[1] = H.ldaq[1]; D.ldbq[0] = H.ldbq[0]; D.ldbq[1] = H.ldbq[1];
+        D.tile_begin = H.tile_begin; D.flags = H.flags;
+    }
+    return D;
+}
+
 // (the two roles are functions of their own: with the producer's lambdas inside the __global__ template hipcc emitted no host
 // stub for the kernel - no diagnostic, an undefined symbol at load time)
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, bool TABLE>
 __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
     using C = RingCfg<BM, BN, S>;
     constexpr int BK = C::BK;
     typedef __attribute__((address_space(3))) void lds_void;
-    auto problem_of = [&](int bpos) { return ring_problem_of(gb, bpos); };
     // ================================ PRODUCER: global -> LDS ring (no registers) ================================
     auto rsrc_of = [](const uint16_t* q, int rows, int ld) {
         const unsigned long long u = reinterpret_cast<unsigned long long>(q);
@@ -1387,7 +1416,7 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
         }
     };
     auto load_desc = [&]() {
-        const GemmHot& H = gb.hot[problem_of(ibpos)];
+        const RingDesc H = ring_desc<TABLE>(gb, ibpos);
         const int tl = ibpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
         im0 = (tl % tiles_m) * BM; in0 = (tl / tiles_m) * BN;
         ink0 = (H.k[0] + BK - 1) / BK; ink = ink0 + (H.k[1] + BK - 1) / BK;
@@ -1465,7 +1494,7 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     int g = 0;
 #pragma unroll 1
     for (int bpos = first; bpos < total_tiles; bpos += grid) {
-        const GemmHot& H = gb.hot[problem_of(bpos)];
+        const RingDesc H = ring_desc<TABLE>(gb, bpos);
         const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt, ++g) {
@@ -1478,11 +1507,10 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     M2F_TS(5);
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, bool TABLE>
 __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
     using C = RingCfg<BM, BN, S>;
     constexpr int MI = BM / 64, NI = BN / 64, BK = C::BK;
-    auto problem_of = [&](int bpos) { return ring_problem_of(gb, bpos); };
     // ==================================== CONSUMER: LDS -> MFMA -> epilogue ====================================
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, x = ((lane & 31) >> 1) & 7;
@@ -1494,9 +1522,8 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
     M2F_TS(0);
 #pragma unroll 1
     for (int bpos = first; bpos < total_tiles; bpos += grid) {
-        const int pi = problem_of(bpos);
-        const GemmHot& H = gb.hot[pi];
-        const GemmProblem& P = gb.pr[pi];
+        const RingDesc H = ring_desc<TABLE>(gb, bpos);
+        const GemmProblem& P = TABLE ? gb.table[H.pi] : gb.pr[H.pi];
         const int tl = bpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
         const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;
         const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
@@ -1557,23 +1584,45 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
         if (reluA) kloop(std::true_type{});
         else kloop(std::false_type{});
         M2F_TS(3);
-        ring_epilogue<MI, NI, BM, BN>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
+        ring_epilogue<MI, NI, BM, BN, TABLE>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
         M2F_TS(4);
     }
     lds_barrier();                                                  // matches the producers' last barrier
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, bool TABLE>
 __global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
     const int total_tiles = gb.total_tiles, grid = (int)gridDim.x;
     const int first = xcd_remap((int)blockIdx.x, grid);
-    if (threadIdx.x >= 256) ring_producer<BM, BN, S>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
-    else ring_consumer<BM, BN, S>(gb, smem, wave, lane, first, grid, total_tiles);
+    if (threadIdx.x >= 256) ring_producer<BM, BN, S, TABLE>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
+    else ring_consumer<BM, BN, S, TABLE>(gb, smem, wave, lane, first, grid, total_tiles);
 }
 
 long long g_ring_launches = 0;         // host-side count of ring-form launches (m2f_gemm_ring_launches: tests check the form engaged)
+
+template <int BM, int BN, int S, bool TABLE>
+hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
+    using C = RingCfg<BM, BN, S>;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    auto kern = m2f_gemm16_ring_kernel<BM, BN, S, TABLE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    ++g_ring_launches;
+    hipLaunchKernelGGL(kern, dim3(t < n_cu ? t : n_cu), dim3(512), C::LDS_ALL, stream, hb);
+    return hipGetLastError();
+}
+
 
 template <int BM, int BN, int S>
 hipError_t launch_ring16(GemmBatch& gb, hipStream_t stream) {
@@ -1600,22 +1649,7 @@ hipError_t launch_ring16(GemmBatch& gb, hipStream_t stream) {
         h.flags = p.flags; h.tile_begin = p.tile_begin; h.has_bias_grad = 0;
     }
     hb.total_tiles = t;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    auto kern = m2f_gemm16_ring_kernel<BM, BN, S>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    ++g_ring_launches;
-    hipLaunchKernelGGL(kern, dim3(t < n_cu ? t : n_cu), dim3(512), C::LDS_ALL, stream, hb);
-    return hipGetLastError();
+    return launch_ring_grid<BM, BN, S, false>(hb, t, stream);
 }
 
 // can this forward-form launch run as the ring form?  (no GELU / FP8 / B-side ReLU epilogue variants there)
@@ -1895,6 +1929,7 @@ extern "C" long long m2f_gemm_ring_launches(void) { return g_ring_launches; }
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
+    if (gb.table_tile == 129) return launch_ring_grid<128, 128, 4, true>(gb, gb.total_tiles, stream);      // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

@@ -96,7 +96,7 @@ struct GemmBatch {
     const GemmProblem* table;
     const uint16_t* tile_prob;
     int total_tiles;
-    int table_tile;           // 64 or 128
+    int table_tile;           // 64, 128, 256 (256x128) or 129 (128x128, ring form)
 };
 #define M2F_SPLITK_MAX_TILES 512
 

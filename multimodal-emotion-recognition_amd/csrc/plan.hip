@@ -1125,11 +1125,15 @@ int build_plan(m2f_plan& P, char* ws_base) {
     }
     int total_tiles = 0;
     // 256x128 tiles (a quarter fewer operand bytes through L1 than 128x128: 145 vs 183 us at C2 once the staging ring kept its
-    // loads in flight).  M2F_TABLE_TILE=64|128 (read when a plan is built) selects the other builds of the table kernel; the
-    // tests run all three against each other
+    // loads in flight).  M2F_TABLE_TILE=64|128 (read when a plan is built) selects the other register-staged builds of the table
+    // kernel, 129 the RING form with 128x128 tiles (gemm.hip, m2f_gemm16_ring_kernel).  The ring form's k-loop is ~2x faster per
+    // workgroup, but this launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together - bytes per
+    // FLOP decide, and the larger tile wins (C3 step 3.655 ms vs 3.707 with the ring form).  The tests run all of them against
+    // each other.
     const char* tt_env = getenv("M2F_TABLE_TILE");
-    const int table_tile = (tt_env && (atoi(tt_env) == 64 || atoi(tt_env) == 128)) ? atoi(tt_env) : 256;
-    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, table_tile, tile_prob);
+    const int tt = tt_env ? atoi(tt_env) : 0;
+    const int table_tile = (tt == 64 || tt == 128 || tt == 129) ? tt : 256;
+    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, table_tile == 129 ? 128 : table_tile, tile_prob);
     if (total_tiles <= 0) table_ok = false;
     GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;
     uint16_t* d_tile_prob = table_ok ? bld.ar.alloc<uint16_t>(tile_prob.size()) : nullptr;

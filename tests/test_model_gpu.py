@@ -209,10 +209,11 @@ def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monke
     assert checked >= 20
 
 
-@pytest.mark.parametrize("tile", ["64", "128"])
+@pytest.mark.parametrize("tile", ["64", "128", "129"])
 def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, tile, monkeypatch):
-    """The persistent weight-gradient table kernel exists as 64x64, 128x128 and 256x128 (default) builds
-    (M2F_TABLE_TILE, read when a plan is built): same operands and k order, so the gradients agree to fp32 summation noise."""
+    """The persistent weight-gradient table launch exists as register-staged 64x64, 128x128 and 256x128 (default) builds and
+    in the ring form (129: 128x128 tiles, LDS-direct staging) (M2F_TABLE_TILE, read when a plan is built): same operands and
+    k order, so the gradients agree to fp32 summation noise."""
     fx = _load(golden_dir, "c2_slice")
     cfg, text, audio, key_pad, emotion = _inputs("c2_slice", fx)
     batch = (text, audio, key_pad, emotion)

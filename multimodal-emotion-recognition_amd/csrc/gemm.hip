@@ -1131,539 +1131,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     gemm16_body<A_RC, B_RC, BM, BN, BK, D, true>(gb);
 }
 
-// Epilogue of the ring form.  The consumers multiplied with the operands SWAPPED (as for table_epilogue_t), so a lane holds, of
-// its 32x32 block, row (lane & 31) and columns 8 g + 4 (lane >> 5) + 0..3 in registers 4 g .. 4 g + 3.  Stored from there, a
-// wave instruction touches 32 different 128-byte lines (measured: 12.9k cycles per 128x128 tile; the row-per-register layout
-// of gemm_epilogue with its 4-byte stores: 7.8k - both far above the tile's 8k cycles of MFMA work).  What the store path
-// wants is whole lines per instruction, so each block makes one pass through a wave-private 4 KiB LDS image (4 ds_write_b128,
-// 16-byte chunks XOR-swizzled by row, then 4 ds_read_b128 in row-major lane order: lane -> row (lane >> 3) + 8 p, columns
-// 4 (lane & 7) + 0..3) and every term of the epilogue - bias, residual, gate, accumulate, C, the bf16 shadow - moves as
-// 16-byte (8-byte for bf16) accesses of 8 lanes per 128-byte row segment.  Per element the operations and their order are
-// those of gemm_epilogue, so both produce the same bits.  `ep` = this wave's 4 KiB of LDS (not part of the operand ring: the
-// producers are already filling that with the next tile).
-// (the descriptor fields are fetched - scalar loads from the kernel argument segment, the shadow map, the RNG state - BEFORE
-// the k-loop: read after it they cost the tile 2k cycles of dependent load latency with the MFMA pipe idle)
-struct RingEpi {
-    int M, N, ldc, ldres, ldgate;
-    const float* bias; const float* res; const float* gate; float* C; uint16_t* C16;
-    float gscale; uint32_t site, key; bool relu_out, accum, vec;
-};
-template <int BM, int BN>
-__device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const GemmProblem& P, int m0, int n0) {
-    RingEpi E;
-    E.M = P.M; E.N = P.N; E.ldc = P.ldc; E.ldres = P.ldres; E.ldgate = P.ldgate;
-    E.bias = P.bias; E.res = P.res; E.gate = P.gate; E.C = P.c;
-    E.C16 = reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c));
-    E.gscale = P.gate_scale;
-    E.relu_out = P.flags & GF_RELU_OUT; E.accum = P.flags & GF_ACCUM;
-    E.site = P.drop_site; E.key = 0;
-    if (E.site) E.key = m2f_site_key(gb.rng, E.site);
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    E.vec = (m0 + BM <= E.M) && (n0 + BN <= E.N) && al16(E.C) && ((E.ldc & 3) == 0) && (!E.bias || al16(E.bias)) &&
-            (!E.res || (al16(E.res) && (E.ldres & 3) == 0)) && (!E.gate || (al16(E.gate) && (E.ldgate & 3) == 0)) &&
-            (!E.C16 || (reinterpret_cast<uintptr_t>(E.C16) & 7) == 0);                  // block-uniform
-    return E;
-}
-
-template <int MI, int NI, int BM, int BN, bool PLAIN = false>      // PLAIN: the launch form has no optional terms (weight-gradient table)
-__device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi& E, f32x16 (&acc)[MI][NI], int m0, int n0,
-                                              int lane, int wm, int wn, char* ep) {
-    const int M = E.M, N = E.N;
-    const float* __restrict__ bias = E.bias;
-    const float* __restrict__ res = E.res;
-    const float* __restrict__ gate = E.gate;
-    float* __restrict__ C = E.C;
-    uint16_t* __restrict__ C16 = E.C16;
-    const int ldc = E.ldc, ldres = E.ldres, ldgate = E.ldgate;
-    const float gscale = E.gscale;
-    const bool relu_out = E.relu_out, accum = E.accum, vec = E.vec;
-    const uint32_t site = E.site, key = E.key;
-    // F = which optional terms this launch has (block-uniform): 1 dropout site, 2 gate, 4 residual, 8 accumulate.  As runtime
-    // branches inside the per-element code they made the epilogue ~45 instructions per element (10k cycles per 128x128
-    // tile, more than its k-loop) and every conditional load was followed by its own full wait; as a template parameter the
-    // absent terms cost nothing - no instructions, no registers.
-    auto element = [&](auto ftag, float a, float bv, float rv, float gv, float cv, int row, int col) {
-        constexpr int F = decltype(ftag)::value;
-        float x = a + bv;
-        x = relu_out ? fmaxf(x, 0.f) : x;
-        if constexpr (F & 1) x = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? x * gb.drop_scale : 0.f;
-        if constexpr (F & 4) x = x + rv; else x = x + 0.f;
-        if constexpr (F & 2) x = gv > 0.f ? x * gscale : 0.f;
-        if constexpr (F & 8) return x + cv; else return x + 0.f;
-    };
-    auto element_rt = [&](float a, float bv, float rv, float gv, float cv, int row, int col) {      // edge tiles
-        float x = a + bv;
-        if (relu_out) x = fmaxf(x, 0.f);
-        if (site) x = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? x * gb.drop_scale : 0.f;
-        x = x + rv;
-        if (gate) x = gv > 0.f ? x * gscale : 0.f;
-        return x + cv;
-    };
-    const int wrow = lane & 31, wq = lane >> 5;                     // as accumulator owner: row, 16-byte chunk 2 g + wq
-    const int rrow = lane >> 3, rq = lane & 7;                      // as row-major reader: row rrow + 8 p, chunk rq
-    if (vec) {
-        // Loads and stores share one in-order counter (vmcnt) on gfx9: a wait for freshly issued loads is also a wait for
-        // every store in front of them, i.e. for a full write round trip per pass (that was 11k cycles per 128x128 tile).
-        // So the optional terms of block b + 1 are requested BEFORE block b is stored, and by the time they are needed
-        // only counted, younger operations are outstanding.
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        struct Terms { f32x4 r[4], g[4], c[4]; };
-        f32x4 bv[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bv[j] = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + j * 32 + 4 * rq) : z;
-        auto blocks = [&](auto ftag) {
-            constexpr int F = decltype(ftag)::value;
-            auto load_terms = [&](int i, int j, Terms& T) {
-                const int rb = m0 + wm * (BM / 2) + i * 32, col = n0 + wn * (BN / 2) + j * 32 + 4 * rq;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int row = rb + rrow + 8 * p;
-                    if constexpr (F & 4) T.r[p] = *reinterpret_cast<const f32x4*>(res + (size_t)((uint32_t)(row * ldres + col)));
-                    if constexpr (F & 2) T.g[p] = *reinterpret_cast<const f32x4*>(gate + (size_t)((uint32_t)(row * ldgate + col)));
-                    if constexpr (F & 8) T.c[p] = *reinterpret_cast<const f32x4*>(C + (size_t)((uint32_t)(row * ldc + col)));
-                }
-            };
-            // (two sets of terms in registers; the 256x128 tile with its 128 accumulator registers affords that for one term)
-            constexpr int NT = ((F >> 1) & 1) + ((F >> 2) & 1) + ((F >> 3) & 1);
-            constexpr bool AHEAD = MI * NI <= 4 || NT <= 1;
-            Terms T[2];
-            if constexpr (AHEAD) load_terms(0, 0, T[0]);
-#pragma unroll
-            for (int b = 0; b < MI * NI; ++b) {
-                const int i = b / NI, j = b % NI;
-                if constexpr (AHEAD) { if (b + 1 < MI * NI) load_terms((b + 1) / NI, (b + 1) % NI, T[(b + 1) & 1]); }
-                else load_terms(i, j, T[b & 1]);
-                if constexpr (NT != 0) __builtin_amdgcn_sched_barrier(0);            // keep them in front of this block's stores
-                const int rb = m0 + wm * (BM / 2) + i * 32, col = n0 + wn * (BN / 2) + j * 32 + 4 * rq;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(ep + wrow * 128 + (((2 * g + wq) ^ (wrow & 7)) << 4)) = v;
-                }
-                asm volatile("" ::: "memory");                      // same wave, in-order LDS queue; pin the compiler's order too
-                __builtin_amdgcn_wave_barrier();
-                f32x4 a[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) a[p] = *reinterpret_cast<const f32x4*>(ep + (rrow + 8 * p) * 128 + ((rq ^ ((rrow + 8 * p) & 7)) << 4));
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                if (b == 0) { M2F_TS(5); }
-                if (b == 1) { M2F_TS(7); }
-                const Terms& t = T[b & 1];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int row = rb + rrow + 8 * p;
-                    const uint32_t oc = (uint32_t)(row * ldc + col);
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = element(ftag, a[p][e], bv[j][e], (F & 4) ? t.r[p][e] : 0.f, (F & 2) ? t.g[p][e] : 1.f, (F & 8) ? t.c[p][e] : 0.f, row, col + e);
-                    *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;
-                    if (C16) {
-                        uint2 hh;
-                        hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
-                        hh.y = (uint32_t)m2f_bf16_bits(v[2]) | ((uint32_t)m2f_bf16_bits(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(C16 + (size_t)oc) = hh;
-                    }
-                }
-                if (b == 0) { M2F_TS(6); }
-            }
-        };
-        const int fmask = PLAIN ? 0 : (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0);
-        if constexpr (PLAIN) blocks(std::integral_constant<int, 0>{});
-        else switch (fmask) {
-#define M2F_RING_EP(F) case F: blocks(std::integral_constant<int, F>{}); break;
-            M2F_RING_EP(0) M2F_RING_EP(1) M2F_RING_EP(2) M2F_RING_EP(3) M2F_RING_EP(4) M2F_RING_EP(5) M2F_RING_EP(6) M2F_RING_EP(7)
-            M2F_RING_EP(8) M2F_RING_EP(9) M2F_RING_EP(10) M2F_RING_EP(11) M2F_RING_EP(12) M2F_RING_EP(13) M2F_RING_EP(14) M2F_RING_EP(15)
-#undef M2F_RING_EP
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int row = m0 + wm * (BM / 2) + i * 32 + wrow, col0 = n0 + wn * (BN / 2) + j * 32 + 4 * wq;
-            if (row < M) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = col0 + 8 * (r >> 2) + (r & 3);
-                    if (col < N) {
-                        const uint32_t oc = (uint32_t)(row * ldc + col);
-                        const float v = element_rt(acc[i][j][r], bias ? bias[col] : 0.f, res ? res[(size_t)((uint32_t)(row * ldres + col))] : 0.f,
-                                                gate ? gate[(size_t)((uint32_t)(row * ldgate + col))] : 1.f, accum ? C[(size_t)oc] : 0.f, row, col);
-                        C[(size_t)oc] = v;
-                        if (C16) C16[(size_t)oc] = m2f_bf16_bits(v);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// =========================================================================================================
-// RING form of the k-contiguous bf16 GEMM (forward / input-gradient launches of a step whose tile count fills the chip).
-//
-// What bounds gemm16_body on these launches is neither L2 nor HBM (profiles/r02: 290-cycle average L1->L2 latency, 84 % L2
-// hits, yet 37 GB/s per CU) but its own pipeline: per k-tile the producers move every operand byte global -> VGPR -> LDS
-// (ds_write_b128: 8 LDS-array cycles per KiB, twice what the fragment reads of the same bytes cost), the consumers read ALL
-// fragments of the k-tile, wait, then run the MFMAs - LDS and MFMA never overlap inside a wave and there is one consumer
-// wave per SIMD.  This form changes both ends:
-//   * staging is LDS-direct (buffer_load_dwordx4 ... lds): no destination registers, no ds_write pass, S k-tiles of
-//     BM x 64 + BN x 64 in a ring (S - 1 in flight per workgroup); out-of-range rows / k-chunks are range-checked away by
-//     the buffer descriptor and land as zeros, so edge tiles need no masks;
-//   * the LDS image is the lane-linear one LDS-DMA produces - 128-byte rows, 16-byte chunk c of row r stored at position
-//     c ^ ((r >> 1) & 7) (the source address is permuted, not the destination) - which makes every ds_read_b128 fragment
-//     read conflict-free (MI355X_MICROARCH.md, LDS table: the four 16-lane groups of a b128 read);
-//   * consumers own (BM/2) x (BN/2) per wave (64x64 or 128x64: 1 KiB or 0.75 KiB of fragments per MFMA instead of 2) and
-//     prefetch the fragments of k-slice s+1 while the MFMAs of slice s run;
-//   * one workgroup barrier per k-tile; the producers run S - 1 k-tiles ahead ACROSS output tiles, so the next tile's
-//     first operands arrive under the epilogue of the current one (persistent tile loop, grid <= number of CUs).
-// Same accumulation order per output element as gemm16_body (k ascending, one MFMA chain) and the same epilogue code,
-// so the results are bit-identical to the 64x64 / 128x128 builds.
-// =========================================================================================================
-typedef __amdgpu_buffer_rsrc_t m2f_rsrc_t;
-template <int BM, int BN, int S>
-struct RingCfg {
-    static constexpr int BK = 64, ROW = BK * 2;
-    static constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, SLOT = A_BYTES + B_BYTES, LDS = S * SLOT;
-    static constexpr int A_INSTR = A_BYTES / 1024 / 4, B_INSTR = B_BYTES / 1024 / 4;     // per producer wave and k-tile (1 KiB = 8 rows each)
-    static constexpr int PER_WAVE = A_INSTR + B_INSTR;
-    static constexpr int LDS_ALL = LDS + 4 * 4096;               // + one 32x32 fp32 epilogue image per consumer wave
-    static_assert(LDS_ALL <= 160 * 1024 && (S - 2) * PER_WAVE <= 63, "LDS budget / vmcnt range");
-};
-
-template <int N>
-__device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-__device__ __forceinline__ int ring_problem_of(const GemmBatch& gb, int bpos) {
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < M2F_GEMM_MAX_PROBLEMS; ++i)
-        if (bpos >= gb.tb[i]) pi = i;
-    return pi;
-}
-
-// The fields both roles need of the problem a tile belongs to.  Grouped launches: the compact header in the kernel arguments.
-// TABLE form (the weight-gradient launch, ~100 problems): tile -> problem through gb.tile_prob, the problem from the device
-// table; the index is made provably uniform so that these are scalar loads.
-struct RingDesc {
-    const uint16_t* aq[2]; const uint16_t* bq[2];
-    int M, N, k[2], ldaq[2], ldbq[2], tile_begin, pi;
-    uint32_t flags;
-};
-template <bool TABLE>
-__device__ __forceinline__ RingDesc ring_desc(const GemmBatch& gb, int bpos) {
-    RingDesc D;
-    if constexpr (TABLE) {
-        D.pi = __builtin_amdgcn_readfirstlane((int)gb.tile_prob[bpos]);
-        const GemmProblem& P = gb.table[D.pi];
-        D.aq[0] = P.a.q[0]; D.aq[1] = P.a.q[0]; D.bq[0] = P.b.q[0]; D.bq[1] = P.b.q[0];
-        D.M = P.M; D.N = P.N; D.k[0] = P.a.k[0]; D.k[1] = 0;
-        D.ldaq[0] = P.a.ldq[0]; D.ldaq[1] = P.a.ldq[0]; D.ldbq[0] = P.b.ldq[0]; D.ldbq[1] = P.b.ldq[0];
-        D.tile_begin = P.tile_begin; D.flags = 0;                   // table problems carry no operand / epilogue options
-    } else {
-        D.pi = ring_problem_of(gb, bpos);
-        const GemmHot& H = gb.hot[D.pi];
-        D.aq[0] = H.aq[0]; D.aq[1] = H.aq[1]; D.bq[0] = H.bq[0]; D.bq[1] = H.bq[1];
-        D.M = H.M; D.N = H.N; D.k[0] = H.k[0]; D.k[1] = H.k[1];
-        D.ldaq[0] = H.ldaq[0]; D.ldaq[1] = H.ldaq[1]; D.ldbq[0] = H.ldbq[0]; D.ldbq[1] = H.ldbq[1];
-        D.tile_begin = H.tile_begin; D.flags = H.flags;
-    }
-    return D;
-}
-
-// (the two roles are functions of their own: with the producer's lambdas inside the __global__ template hipcc emitted no host
-// stub for the kernel - no diagnostic, an undefined symbol at load time)
-template <int BM, int BN, int S, bool TABLE>
-__device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
-    using C = RingCfg<BM, BN, S>;
-    constexpr int BK = C::BK;
-    typedef __attribute__((address_space(3))) void lds_void;
-    // ================================ PRODUCER: global -> LDS ring (no registers) ================================
-    auto rsrc_of = [](const uint16_t* q, int rows, int ld) {
-        const unsigned long long u = reinterpret_cast<unsigned long long>(q);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
-                                                 __builtin_amdgcn_readfirstlane(rows * ld * 2), 0x00020000);
-    };
-    constexpr unsigned OOB = 0x80000000u;
-    // lane -> (row within the 8-row piece, chunk position); the chunk stored at this position is pos ^ ((row >> 1) & 7)
-    const int lrow = lane >> 3, pos = lane & 7;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);       // provably uniform: LDS destinations go through M0
-    // issue cursor: k-tile ikt of output tile ibpos goes to ring slot islot.  Per (tile, segment) the byte offset of
-    // every piece's lane at k = 0 is kept in registers, a k-tile adds one uniform term: one v_add per load in the loop
-    int ibpos = first, ikt = 0, islot = 0, issued = 0;
-    int im0 = 0, in0 = 0, ink0 = 0, ink = 0, kp0 = 0, kp1 = 0, ald0 = 0, ald1 = 0, bld0 = 0, bld1 = 0;
-    unsigned offA[C::A_INSTR], offB[C::B_INSTR];
-    int kpad = 0, kcur = 0;                                     // current segment: padded length, k of the next k-tile
-    m2f_rsrc_t ra0, ra1, rb0, rb1, ra, rb;
-    bool idone = ibpos >= total_tiles;
-    M2F_TS(0);
-    auto set_segment = [&](int seg) {
-        const int lda = seg ? ald1 : ald0, ldb = seg ? bld1 : bld0;
-        if (seg) { ra = ra1; rb = rb1; } else { ra = ra0; rb = rb0; }
-        kpad = seg ? kp1 : kp0; kcur = 0;
-#pragma unroll
-        for (int j = 0; j < C::A_INSTR; ++j) {
-            const int r = (wv * C::A_INSTR + j) * 8 + lrow;             // row within the tile
-            offA[j] = (unsigned)((im0 + r) * lda + 8 * (pos ^ ((r >> 1) & 7))) * 2u;
-        }
-#pragma unroll
-        for (int j = 0; j < C::B_INSTR; ++j) {
-            const int r = (wv * C::B_INSTR + j) * 8 + lrow;
-            offB[j] = (unsigned)((in0 + r) * ldb + 8 * (pos ^ ((r >> 1) & 7))) * 2u;
-        }
-    };
-    auto load_desc = [&]() {
-        const RingDesc H = ring_desc<TABLE>(gb, ibpos);
-        const int tl = ibpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
-        im0 = (tl % tiles_m) * BM; in0 = (tl / tiles_m) * BN;
-        ink0 = (H.k[0] + BK - 1) / BK; ink = ink0 + (H.k[1] + BK - 1) / BK;
-        kp0 = (H.k[0] + 7) & ~7; kp1 = (H.k[1] + 7) & ~7;
-        ald0 = H.ldaq[0]; ald1 = H.ldaq[1]; bld0 = H.ldbq[0]; bld1 = H.ldbq[1];
-        const bool two = H.k[1] > 0;
-        ra0 = rsrc_of(H.aq[0], H.M, ald0); rb0 = rsrc_of(H.bq[0], H.N, bld0);
-        ra1 = rsrc_of(two ? H.aq[1] : H.aq[0], H.M, two ? ald1 : ald0);
-        rb1 = rsrc_of(two ? H.bq[1] : H.bq[0], H.N, two ? bld1 : bld0);
-        set_segment(0);
-    };
-    if (!idone) load_desc();
-    auto issue_next = [&]() {
-        if (ikt == ink0 && ikt > 0) set_segment(1);
-        char* dstA = smem + islot * C::SLOT + wv * (C::A_INSTR * 1024);
-        char* dstB = smem + islot * C::SLOT + C::A_BYTES + wv * (C::B_INSTR * 1024);
-        const unsigned kb = (unsigned)kcur * 2u;
-#if defined(M2F_RING_EXP) && M2F_RING_EXP == 1      // experiment: no loads (consumer floor)
-        if (false) {
-#else
-        if (kcur + BK <= kpad) {
-#endif                                // whole k-tile inside the (padded) reduction length
-#pragma unroll
-            for (int j = 0; j < C::A_INSTR; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dstA + j * 1024), 16, offA[j] + kb, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < C::B_INSTR; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(dstB + j * 1024), 16, offB[j] + kb, 0, 0, 0);
-#if defined(M2F_RING_EXP) && M2F_RING_EXP == 1
-        } else if (false) {
-#else
-        } else {                                                // tail k-tile: chunks past the padded length land as zeros
-#endif
-#pragma unroll
-            for (int j = 0; j < C::A_INSTR; ++j) {
-                const int r = (wv * C::A_INSTR + j) * 8 + lrow;
-                const bool in = kcur + 8 * (pos ^ ((r >> 1) & 7)) < kpad;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dstA + j * 1024), 16, in ? offA[j] + kb : OOB, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < C::B_INSTR; ++j) {
-                const int r = (wv * C::B_INSTR + j) * 8 + lrow;
-                const bool in = kcur + 8 * (pos ^ ((r >> 1) & 7)) < kpad;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(dstB + j * 1024), 16, in ? offB[j] + kb : OOB, 0, 0, 0);
-            }
-        }
-        kcur += BK;
-        ++issued;
-        islot = islot + 1 == S ? 0 : islot + 1;
-        if (++ikt == ink) {
-            ikt = 0; ibpos += grid;
-            idone = ibpos >= total_tiles;
-            if (!idone) load_desc();
-        }
-    };
-    // k-tile g (counted over this workgroup's whole tile sequence) has landed once at most the pieces issued after it
-    // are outstanding: loads of one wave complete in issue order
-    auto wait_landed = [&](int g) {
-        const int younger = issued - (g + 1);
-        if (younger <= 0) ring_wait_vm<0>();
-        else if (younger == 1) ring_wait_vm<C::PER_WAVE>();
-        else if (S < 4 || younger == 2) ring_wait_vm<(S > 3 ? 2 : 1) * C::PER_WAVE>();
-        else ring_wait_vm<(S > 4 ? 3 : 1) * C::PER_WAVE>();
-    };
-    static_assert(S >= 3 && S <= 5, "ring depth");
-#pragma unroll 1
-    M2F_TS(1);
-    for (int t = 0; t < S - 1; ++t)
-        if (!idone) issue_next();
-    M2F_TS(2);
-    wait_landed(0);
-    M2F_TS(3);
-    lds_barrier();                                              // (#0) k-tile 0 is in the ring
-    M2F_TS(4);
-    int g = 0;
-#pragma unroll 1
-    for (int bpos = first; bpos < total_tiles; bpos += grid) {
-        const RingDesc H = ring_desc<TABLE>(gb, bpos);
-        const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            // the consumers multiply k-tile g; the slot of k-tile g - 1 was released at the last barrier
-            if (!idone) issue_next();
-            if (issued > g + 1) wait_landed(g + 1);
-            lds_barrier();                                      // (#g+1)
-        }
-    }
-    M2F_TS(5);
-}
-
-template <int BM, int BN, int S, bool TABLE>
-__device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
-    using C = RingCfg<BM, BN, S>;
-    constexpr int MI = BM / 64, NI = BN / 64, BK = C::BK;
-    // ==================================== CONSUMER: LDS -> MFMA -> epilogue ====================================
-    const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5, x = ((lane & 31) >> 1) & 7;
-    int fo[BK / 16];                                            // swizzled chunk offset of k-slice ks for this lane
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) fo[ks] = ((2 * ks + h) ^ x) << 4;
-    const int arow = (wm * (BM / 2) + (lane & 31)) * C::ROW, brow = C::A_BYTES + (wn * (BN / 2) + (lane & 31)) * C::ROW;
-    int slot = 0;
-    M2F_TS(0);
-#pragma unroll 1
-    for (int bpos = first; bpos < total_tiles; bpos += grid) {
-        const RingDesc H = ring_desc<TABLE>(gb, bpos);
-        const GemmProblem& P = TABLE ? gb.table[H.pi] : gb.pr[H.pi];
-        const int tl = bpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
-        const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;
-        const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
-        const bool reluA = H.flags & GF_RELU_A;
-        f32x16 acc[MI][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // the ReLU-on-A variant (block-uniform) gets its own copy of the loop: a branch inside would cut the k-tile into
-        // basic blocks and keep the scheduler from interleaving fragment reads and MFMAs
-        auto kloop = [&](auto relu_tag) {
-            constexpr bool RELU = decltype(relu_tag)::value;
-#pragma unroll 1
-            for (int kt = 0; kt < nk; ++kt) {
-                lds_barrier();                                      // (#g) k-tile g has landed
-                const char* ab = smem + slot * C::SLOT + arow;
-                const char* bb = smem + slot * C::SLOT + brow;
-                constexpr int KS = BK / 16;
-                bf16x8 fa[2][MI], fb[2][NI];
-                auto frags = [&](int ks, int buf) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * C::ROW + fo[ks]);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * C::ROW + fo[ks]);
-                    if constexpr (RELU) {                           // relu(cat(x, text)) of the fusion layer's Linear
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) {
-                            m2f_u32x4 w = __builtin_bit_cast(m2f_u32x4, fa[buf][i]);
-                            w.x = relu_bf16x2(w.x); w.y = relu_bf16x2(w.y); w.z = relu_bf16x2(w.z); w.w = relu_bf16x2(w.w);
-                            fa[buf][i] = __builtin_bit_cast(bf16x8, w);
-                        }
-                    }
-                };
-#if defined(M2F_RING_EXP) && M2F_RING_EXP == 2      // experiment: no fragment reads / MFMAs (producer floor)
-                if (false)
-#endif
-                {
-                frags(0, 0);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (ks + 1 < KS) frags(ks + 1, (ks + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);              // the next slice's reads go out BEFORE this slice's MFMAs
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);   // operands swapped: ring_epilogue
-                }
-                }
-                slot = slot + 1 == S ? 0 : slot + 1;
-            }
-        };
-        const RingEpi E = ring_epilogue_args<BM, BN>(gb, P, m0, n0);
-        M2F_TS(1);
-        if (reluA) kloop(std::true_type{});
-        else kloop(std::false_type{});
-        M2F_TS(3);
-        ring_epilogue<MI, NI, BM, BN, TABLE>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
-        M2F_TS(4);
-    }
-    lds_barrier();                                                  // matches the producers' last barrier
-}
-
-template <int BM, int BN, int S, bool TABLE>
-__global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
-    const int total_tiles = gb.total_tiles, grid = (int)gridDim.x;
-    const int first = xcd_remap((int)blockIdx.x, grid);
-    if (threadIdx.x >= 256) ring_producer<BM, BN, S, TABLE>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
-    else ring_consumer<BM, BN, S, TABLE>(gb, smem, wave, lane, first, grid, total_tiles);
-}
-
-long long g_ring_launches = 0;         // host-side count of ring-form launches (m2f_gemm_ring_launches: tests check the form engaged)
-
-template <int BM, int BN, int S, bool TABLE>
-hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
-    using C = RingCfg<BM, BN, S>;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    auto kern = m2f_gemm16_ring_kernel<BM, BN, S, TABLE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    ++g_ring_launches;
-    hipLaunchKernelGGL(kern, dim3(t < n_cu ? t : n_cu), dim3(512), C::LDS_ALL, stream, hb);
-    return hipGetLastError();
-}
-
-
-template <int BM, int BN, int S>
-hipError_t launch_ring16(GemmBatch& gb, hipStream_t stream) {
-    using C = RingCfg<BM, BN, S>;
-    int t = 0;
-    for (int i = 0; i < gb.count; ++i) {
-        GemmProblem& p = gb.pr[i];
-        p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0;
-        p.tile_begin = t;
-        p.tiles_n = m2f_cdiv(p.N, BN);
-        t += m2f_cdiv(p.M, BM) * p.tiles_n;
-    }
-    if (t == 0) return hipSuccess;
-    GemmBatch hb = gb;
-    for (int i = 0; i < M2F_GEMM_MAX_PROBLEMS; ++i) {
-        hb.tb[i] = i < gb.count ? gb.pr[i].tile_begin : 0x7fffffff;
-        GemmHot& h = hb.hot[i];
-        memset(&h, 0, sizeof(h));
-        if (i >= gb.count) continue;
-        const GemmProblem& p = gb.pr[i];
-        h.aq[0] = p.a.q[0]; h.aq[1] = p.a.q[1]; h.bq[0] = p.b.q[0]; h.bq[1] = p.b.q[1];
-        h.M = p.M; h.N = p.N; h.k[0] = p.a.k[0]; h.k[1] = p.a.k[1];
-        h.ldaq[0] = p.a.ldq[0]; h.ldaq[1] = p.a.ldq[1]; h.ldbq[0] = p.b.ldq[0]; h.ldbq[1] = p.b.ldq[1];
-        h.flags = p.flags; h.tile_begin = p.tile_begin; h.has_bias_grad = 0;
-    }
-    hb.total_tiles = t;
-    return launch_ring_grid<BM, BN, S, false>(hb, t, stream);
-}
-
-// can this forward-form launch run as the ring form?  (no GELU / FP8 / B-side ReLU epilogue variants there)
-bool ring_ok(const GemmBatch& gb) {
-    for (int i = 0; i < gb.count; ++i) {
-        const GemmProblem& p = gb.pr[i];
-        if ((p.flags & (GF_GELU_OUT | GF_RELU_B)) || p.c8 || p.bias_grad) return false;
-        for (int sgm = 0; sgm < 2; ++sgm) {
-            if ((size_t)p.M * p.a.ldq[sgm] * 2 >= 0x80000000ull || (size_t)p.N * p.b.ldq[sgm] * 2 >= 0x80000000ull) return false;
-        }
-    }
-    return true;
-}
-
 template <bool A_RC, bool B_RC, int BM, int BN, int BK, int D, bool DENSE = false, bool GELU = false, bool FP8 = false>
 hipError_t launch_cfg16(const GemmBatch& gb, int total_tiles, hipStream_t stream) {
     constexpr int lds = 2 * (A_RC ? Stage16RC<BM, BK>::LDS_BYTES : Stage16KC<BM, BK>::LDS_BYTES) +
@@ -1802,13 +1269,23 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
     // (RoBERTa-large geometry, 512 utterances x 64 tokens: 59.3 -> 55.7 ms per forward)
     if (tile == 128 && !A_RC && !B_RC && count_tiles(256, 128) >= 1024) tile = 256;
     if constexpr (!A_RC && !B_RC) {
-        // Launches with at least ~one 128x128 tile per CU run the ring form (m2f_gemm16_ring_kernel): measured on MI355X, C3
-        // step (B = 64): fwd+bwd 3.21 -> 3.06 ms with the threshold at 200 tiles (3.07 / 3.07 / 3.16 at 100 / 150 / 260),
-        // nothing gained or lost at C2, whose launches stay below it.  Smaller launches keep the 64x64 build, whose 4x
-        // larger tile count fills the chip.  M2F_RING=0 switches the form off, M2F_RING_MIN moves the threshold.
+        // Forward-form launches run the ring form (gemm_ring.h, m2f_gemm16_ring_kernel): 128x128 tiles from ~one tile per CU
+        // on, 128x64 tiles below that while those still cover most of the chip, 64x64 tiles for the rest down to 80 tiles;
+        // what remains (a few tiles, e.g. the classifier) keeps the register-staged 64x64 build below.  Measured on MI355X,
+        // fwd+bwd of the C3 step (B = 64): 3.21 ms without the ring form; 3.06 with the 128x128 form from 200 tiles (3.07 /
+        // 3.07 / 3.16 at 100 / 150 / 260); 2.91 with the 128x64 form from 150 tiles on top (2.95 / 2.91 at 200 / 100); 2.89
+        // with the 64x64 form from 80 tiles (no change down to 1).  C2 (B = 32): 1.957 -> 1.914 -> 1.853 (the 128x64 form
+        // from 100 tiles: 2.014 - launches of ~100 tiles leave too many CUs idle).  M2F_RING=0 switches the form off,
+        // M2F_RING_MIN / M2F_RING64_MIN / M2F_RING32_MIN move the thresholds.
         static const int ring = getenv("M2F_RING") ? atoi(getenv("M2F_RING")) : 1;
         static const int ring_min = getenv("M2F_RING_MIN") ? atoi(getenv("M2F_RING_MIN")) : 200;
-        if (ring && auto_tile && ring_ok(gb) && count_tiles(128, 128) >= ring_min) return launch_ring16<128, 128, 4>(gb, stream);
+        static const int ring64_min = getenv("M2F_RING64_MIN") ? atoi(getenv("M2F_RING64_MIN")) : 150;
+        static const int ring32_min = getenv("M2F_RING32_MIN") ? atoi(getenv("M2F_RING32_MIN")) : 80;
+        if (ring && auto_tile && m2f_gemm_ring_ok(gb)) {
+            if (count_tiles(128, 128) >= ring_min) return m2f_launch_gemm_ring(gb, 128, 128, stream);
+            if (count_tiles(128, 64) >= ring64_min) return m2f_launch_gemm_ring(gb, 128, 64, stream);
+            if (count_tiles(64, 64) >= ring32_min) return m2f_launch_gemm_ring(gb, 64, 64, stream);
+        }
     }
     const int tile_m = tile, tile_n = tile == 256 ? 128 : tile;
     int t = 0;
@@ -1925,11 +1402,9 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 }
 #endif
 
-extern "C" long long m2f_gemm_ring_launches(void) { return g_ring_launches; }
-
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile == 129) return launch_ring_grid<128, 128, 4, true>(gb, gb.total_tiles, stream);      // 128x128 tiles, ring form
+    if (gb.table_tile == 129) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

@@ -100,6 +100,11 @@ struct GemmBatch {
 };
 #define M2F_SPLITK_MAX_TILES 512
 
+// RING form of the k-contiguous bf16 GEMM (gemm_ring.h): bm x bn = 128x128 or 128x64; the table form walks gb.table.
+bool m2f_gemm_ring_ok(const GemmBatch& gb);
+hipError_t m2f_launch_gemm_ring(GemmBatch& gb, int bm, int bn, hipStream_t stream);
+hipError_t m2f_launch_gemm_ring_table(const GemmBatch& gb, hipStream_t stream);
+
 // Launches one grouped GEMM. Returns hipSuccess or the launch error. `tile` = 0 (auto), 64 or 128.
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream);
 // TABLE form, bf16 mode, k-contiguous (NT) operands staged from gb.table[i].{a,b}.q.  Host-side preparation of a table:

@@ -5,9 +5,9 @@ Both forms add the products of one output element in the same order (k ascending
 same epilogue operations per element, so the results must be IDENTICAL BIT FOR BIT - for every epilogue term (bias, ReLU,
 residual, gate, accumulate, dropout), for two-segment reductions (the fusion layer's cat(x, text) operand), for ragged edges
 (rows / columns / reduction lengths that are no multiple of the tile) and for outputs whose leading dimension rules out
-16-byte stores.  `tile=64` pins the 64x64 build; `tile=0` (automatic) takes the ring form once the launch has at least
-M2F_RING_MIN (200) tiles of 128x128 - asserted through m2f_gemm_ring_launches().  The 64x64 build itself is pinned to fp32
-torch references by tests/test_kernels_gpu.py.
+16-byte stores.  `tile=64` pins the register-staged 64x64 build; `tile=0` (automatic) takes the ring form: 128x128 tiles from
+200 such tiles on, 128x64 tiles from 150, 64x64 tiles from 80 (csrc/gemm.hip, launch_tile16) - asserted through
+m2f_gemm_ring_launches().  The register-staged build itself is pinned to fp32 torch references by tests/test_kernels_gpu.py.
 """
 import os
 
@@ -40,20 +40,26 @@ def _both(**kw):
     return outs
 
 
+# N per tile configuration at M ~ 1024: 8 x 26 = 208 tiles of 128x128 | 8 x 21 = 168 of 128x64 (88 of 128x128) | 16 x 8 = 128 of
+# 64x64 (64 of 128x64)
+WIDTH = {"128x128": 3328, "128x64": 1344, "64x64": 512}
+
+
 @pytest.mark.skipif(os.environ.get("M2F_RING", "1") == "0", reason="ring form switched off in the environment")
+@pytest.mark.parametrize("form", sorted(WIDTH))
 @pytest.mark.parametrize("case", ["plain", "ragged_scalar_stores", "ragged_vector_stores", "bias_relu", "residual_dropout",
                                   "gate_accumulate", "all_terms", "two_segments_relu_a", "short_k"])
-def test_ring_form_equals_64x64_build_bit_for_bit(case):
-    g = torch.Generator(device=DEV).manual_seed(sum(map(ord, case)))
+def test_ring_form_equals_64x64_build_bit_for_bit(case, form):
+    g = torch.Generator(device=DEV).manual_seed(sum(map(ord, case + form)))
     rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
-    M, N, K = 1024, 3328, 1024
+    M, N, K = 1024, WIDTH[form], 1024
     kw = {}
     if case == "ragged_scalar_stores":
-        M, N, K = 1001, 3330, 200                   # ldc % 4 != 0: no 16-byte stores anywhere; k tail of 8 (one chunk)
+        M, N, K = 1001, N + 2, 200                  # ldc % 4 != 0: no 16-byte stores anywhere; k tail of 8 (one chunk)
     elif case == "ragged_vector_stores":
-        M, N, K = 1001, 3336, 1000                  # interior tiles vectorised, edge tiles element-wise; k tail of 40
+        M, N, K = 1001, N + 8, 1000                 # interior tiles vectorised, edge tiles element-wise; k tail of 40
     elif case == "short_k":
-        M, N, K = 2048, 2048, 40                    # fewer k-tiles than ring slots
+        K = 40                                      # fewer k-tiles than ring slots
     a, b = rn(M, K), rn(N, K)
     if case in ("bias_relu", "all_terms", "ragged_scalar_stores", "ragged_vector_stores"):
         kw.update(bias=rn(N), relu_out=True)
@@ -72,9 +78,9 @@ def test_ring_form_equals_64x64_build_bit_for_bit(case):
 @pytest.mark.skipif(os.environ.get("M2F_RING", "1") == "0", reason="ring form switched off in the environment")
 def test_ring_form_is_not_taken_below_the_threshold_or_for_pinned_tiles():
     from mer_amd import functional as F, runtime
-    a, b = torch.randn(512, 256, device=DEV), torch.randn(768, 256, device=DEV)
+    a, b = torch.randn(256, 256, device=DEV), torch.randn(448, 256, device=DEV)
     before = _ring_count()
-    F.gemm(a, b, F.NT, runtime.BF16, src16=True)              # 24 tiles of 128x128: the 64x64 build
+    F.gemm(a, b, F.NT, runtime.BF16, src16=True)              # 28 tiles of 64x64: the register-staged 64x64 build
     F.gemm(a, b, F.NT, runtime.F32)                            # fp32 mode never
     torch.cuda.synchronize()
     assert _ring_count() == before

@@ -1374,14 +1374,14 @@ hipError_t launch_table16(const GemmBatch& gb, hipStream_t stream) {
 
 }  // namespace
 
-int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob) {
+int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob, bool operand_options) {
     // tile = 64: 64x64, 128: 128x128, 256: 256 (M) x 128 (N)
     const int tile_m = tile, tile_n = tile == 256 ? 128 : tile;
     tile_prob.clear();
     if (prs.size() > 65535) return -1;
     for (const GemmProblem& p : prs)
-        if ((p.flags & (GF_RELU_A | GF_RELU_B | GF_RELU_OUT | GF_ACCUM | GF_GELU_OUT)) || p.bias || p.res || p.gate || p.drop_site ||
-            p.c8 || p.a.k[1] || p.b.k[1])
+        if ((p.flags & (GF_RELU_OUT | GF_ACCUM | GF_GELU_OUT)) || (!operand_options && ((p.flags & (GF_RELU_A | GF_RELU_B)) || p.bias_grad)) ||
+            p.bias || p.res || p.gate || p.drop_site || p.c8 || p.a.k[1] || p.b.k[1])
             return -1;       // the table kernel stages operands as they are (store_select) and stores plain results (table_epilogue_t)
     int t = 0;
     for (size_t i = 0; i < prs.size(); ++i) {
@@ -1404,7 +1404,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile == 129) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
+    if (gb.table_tile == 129 || gb.table_tile == 130) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

@@ -22,6 +22,10 @@ __device__ unsigned long long m2f_ring_dbg[64];
 #endif
 
 typedef unsigned int ring_u32x4 __attribute__((ext_vector_type(4)));
+typedef short ring_s16x4 __attribute__((ext_vector_type(4)));
+typedef short ring_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float ring_bf16lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float ring_bf16hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 __device__ __forceinline__ uint32_t ring_relu_bf16x2(uint32_t v) {
     const uint32_t m = ((v >> 15) & 0x00010001u) * 0xFFFFu;      // 0xFFFF in every half whose sign bit is set
     return v & ~m;
@@ -258,6 +262,7 @@ struct RingDesc {
     const uint16_t* aq[2]; const uint16_t* bq[2];
     int M, N, k[2], ldaq[2], ldbq[2], tile_begin, pi;
     uint32_t flags;
+    float* bias_grad;           // TABLE + RC form only (the weight-gradient launch sums the bias gradients itself)
 };
 template <bool TABLE>
 __device__ __forceinline__ RingDesc ring_desc(const GemmBatch& gb, int bpos) {
@@ -268,21 +273,21 @@ __device__ __forceinline__ RingDesc ring_desc(const GemmBatch& gb, int bpos) {
         D.aq[0] = P.a.q[0]; D.aq[1] = P.a.q[0]; D.bq[0] = P.b.q[0]; D.bq[1] = P.b.q[0];
         D.M = P.M; D.N = P.N; D.k[0] = P.a.k[0]; D.k[1] = 0;
         D.ldaq[0] = P.a.ldq[0]; D.ldaq[1] = P.a.ldq[0]; D.ldbq[0] = P.b.ldq[0]; D.ldbq[1] = P.b.ldq[0];
-        D.tile_begin = P.tile_begin; D.flags = 0;                   // table problems carry no operand / epilogue options
+        D.tile_begin = P.tile_begin; D.flags = P.flags; D.bias_grad = P.bias_grad;      // (k-contiguous tables carry neither)
     } else {
         D.pi = ring_problem_of(gb, bpos);
         const GemmHot& H = gb.hot[D.pi];
         D.aq[0] = H.aq[0]; D.aq[1] = H.aq[1]; D.bq[0] = H.bq[0]; D.bq[1] = H.bq[1];
         D.M = H.M; D.N = H.N; D.k[0] = H.k[0]; D.k[1] = H.k[1];
         D.ldaq[0] = H.ldaq[0]; D.ldaq[1] = H.ldaq[1]; D.ldbq[0] = H.ldbq[0]; D.ldbq[1] = H.ldbq[1];
-        D.tile_begin = H.tile_begin; D.flags = H.flags;
+        D.tile_begin = H.tile_begin; D.flags = H.flags; D.bias_grad = nullptr;
     }
     return D;
 }
 
 // (the two roles are functions of their own: with the producer's lambdas inside the __global__ template hipcc emitted no host
 // stub for the kernel - no diagnostic, an undefined symbol at load time)
-template <int BM, int BN, int S, bool TABLE>
+template <int BM, int BN, int S, bool TABLE, bool RC>
 __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
     using C = RingCfg<BM, BN, S>;
     constexpr int BK = C::BK;
@@ -304,6 +309,7 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     int im0 = 0, in0 = 0, ink0 = 0, ink = 0, kp0 = 0, kp1 = 0, ald0 = 0, ald1 = 0, bld0 = 0, bld1 = 0;
     unsigned offA[C::A_INSTR], offB[C::B_INSTR];
     int kpad = 0, kcur = 0;                                     // current segment: padded length, k of the next k-tile
+    unsigned stepA = 0, stepB = 0;                              // RC form: bytes per k-tile step (BK rows)
     m2f_rsrc_t ra0, ra1, rb0, rb1, ra, rb;
     bool idone = ibpos >= total_tiles;
     M2F_TS(0);
@@ -311,6 +317,22 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
         const int lda = seg ? ald1 : ald0, ldb = seg ? bld1 : bld0;
         if (seg) { ra = ra1; rb = rb1; } else { ra = ra0; rb = rb0; }
         kpad = seg ? kp1 : kp0; kcur = 0;
+        if constexpr (RC) {
+            // RC operands ([k][row] in memory, e.g. the [token][feature] activations of the weight-gradient launch): the LDS
+            // image is k-major, 256-byte rows of 128 features; a 1 KiB piece = 4 k-rows, lane -> (k-row lane >> 4, chunk
+            // position lane & 15), the 16-byte chunk stored at a position is pos ^ (4 * (k-row & 3)) - which spreads the four
+            // k-rows of a transposing fragment read (ds_read_b64_tr_b16) over four disjoint bank ranges
+            static_assert(!RC || (BM == 128 && BN == 128), "RC form: 256-byte tile rows");
+            const int kr = lane >> 4, p16 = lane & 15;
+#pragma unroll
+            for (int j = 0; j < C::A_INSTR; ++j)
+                offA[j] = (unsigned)(((wv * C::A_INSTR + j) * 4 + kr) * lda + im0) * 2u + 16u * (unsigned)(p16 ^ (4 * kr));
+#pragma unroll
+            for (int j = 0; j < C::B_INSTR; ++j)
+                offB[j] = (unsigned)(((wv * C::B_INSTR + j) * 4 + kr) * ldb + in0) * 2u + 16u * (unsigned)(p16 ^ (4 * kr));
+            stepA = (unsigned)(BK * lda) * 2u; stepB = (unsigned)(BK * ldb) * 2u;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < C::A_INSTR; ++j) {
             const int r = (wv * C::A_INSTR + j) * 8 + lrow;             // row within the tile
@@ -330,7 +352,8 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
         kp0 = (H.k[0] + 7) & ~7; kp1 = (H.k[1] + 7) & ~7;
         ald0 = H.ldaq[0]; ald1 = H.ldaq[1]; bld0 = H.ldbq[0]; bld1 = H.ldbq[1];
         const bool two = H.k[1] > 0;
-        ra0 = rsrc_of(H.aq[0], H.M, ald0); rb0 = rsrc_of(H.bq[0], H.N, bld0);
+        // (RC form: the rows of the buffer are the k index - loads past the reduction length are range-checked to zero)
+        ra0 = rsrc_of(H.aq[0], RC ? H.k[0] : H.M, ald0); rb0 = rsrc_of(H.bq[0], RC ? H.k[0] : H.N, bld0);
         ra1 = rsrc_of(two ? H.aq[1] : H.aq[0], H.M, two ? ald1 : ald0);
         rb1 = rsrc_of(two ? H.bq[1] : H.bq[0], H.N, two ? bld1 : bld0);
         set_segment(0);
@@ -340,6 +363,15 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
         if (ikt == ink0 && ikt > 0) set_segment(1);
         char* dstA = smem + islot * C::SLOT + wv * (C::A_INSTR * 1024);
         char* dstB = smem + islot * C::SLOT + C::A_BYTES + wv * (C::B_INSTR * 1024);
+        if constexpr (RC) {
+            const unsigned ka = (unsigned)(kcur / BK) * stepA, kbb = (unsigned)(kcur / BK) * stepB;
+#pragma unroll
+            for (int j = 0; j < C::A_INSTR; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dstA + j * 1024), 16, offA[j] + ka, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < C::B_INSTR; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(dstB + j * 1024), 16, offB[j] + kbb, 0, 0, 0);
+        } else {
         const unsigned kb = (unsigned)kcur * 2u;
 #if defined(M2F_RING_EXP) && M2F_RING_EXP == 1      // experiment: no loads (consumer floor)
         if (false) {
@@ -369,6 +401,7 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
                 const bool in = kcur + 8 * (pos ^ ((r >> 1) & 7)) < kpad;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(dstB + j * 1024), 16, in ? offB[j] + kb : OOB, 0, 0, 0);
             }
+        }
         }
         kcur += BK;
         ++issued;
@@ -414,7 +447,7 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     M2F_TS(5);
 }
 
-template <int BM, int BN, int S, bool TABLE>
+template <int BM, int BN, int S, bool TABLE, bool RC>
 __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
     using C = RingCfg<BM, BN, S>;
     constexpr int MI = BM / 64, NI = BN / 64, BK = C::BK;
@@ -425,6 +458,18 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) fo[ks] = ((2 * ks + h) ^ x) << 4;
     const int arow = (wm * (BM / 2) + (lane & 31)) * C::ROW, brow = C::A_BYTES + (wn * (BN / 2) + (lane & 31)) * C::ROW;
+    // RC form (k-major image, 256-byte rows): per 16-lane group g, lane 4 q + p supplies the address of k-row
+    // 8 (g >> 1) + q (+ 4 for the second read), features 16 (g & 1) + 4 p .. + 3 of the 32-feature block; lane i of the
+    // group receives feature i.  Chunk index of those 8 bytes = (block base + 16 (g & 1)) / 8 + (p >> 1), XOR 4 q (the image's swizzle).
+    int rc_row = 0, rc_a[MI], rc_b[NI];
+    {
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        rc_row = (8 * (g >> 1) + q) * 256 + 8 * (pp & 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) rc_a[i] = (((wm * (BM / 2) + i * 32 + 16 * (g & 1)) / 8 + (pp >> 1)) ^ (4 * q)) << 4;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rc_b[j] = (((wn * (BN / 2) + j * 32 + 16 * (g & 1)) / 8 + (pp >> 1)) ^ (4 * q)) << 4;
+    }
     int slot = 0;
     M2F_TS(0);
 #pragma unroll 1
@@ -434,7 +479,11 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
         const int tl = bpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
         const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;
         const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
-        const bool reluA = H.flags & GF_RELU_A;
+        const bool reluA = H.flags & GF_RELU_A, reluB = RC && (H.flags & GF_RELU_B);
+        const bool bgrad = RC && H.bias_grad && n0 == 0 && wn == 0;      // wave-uniform: this wave sums its rows of A over k
+        float bsum[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -442,10 +491,15 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // the ReLU-on-A variant (block-uniform) gets its own copy of the loop: a branch inside would cut the k-tile into
-        // basic blocks and keep the scheduler from interleaving fragment reads and MFMAs
-        auto kloop = [&](auto relu_tag) {
-            constexpr bool RELU = decltype(relu_tag)::value;
+        // the operand options (block-uniform: ReLU on A / on B, bias-gradient sums) select a copy of the loop: a branch inside
+        // would cut the k-tile into basic blocks and keep the scheduler from interleaving fragment reads and MFMAs
+        auto kloop = [&](auto ra_tag, auto rb_tag, auto bg_tag) {
+            constexpr bool RELU_A = decltype(ra_tag)::value, RELU_B = decltype(rb_tag)::value, BGRAD = decltype(bg_tag)::value;
+            auto relu8 = [](bf16x8 f) {
+                ring_u32x4 w = __builtin_bit_cast(ring_u32x4, f);
+                w.x = ring_relu_bf16x2(w.x); w.y = ring_relu_bf16x2(w.y); w.z = ring_relu_bf16x2(w.z); w.w = ring_relu_bf16x2(w.w);
+                return __builtin_bit_cast(bf16x8, w);
+            };
 #pragma unroll 1
             for (int kt = 0; kt < nk; ++kt) {
                 ring_lds_barrier();                                      // (#g) k-tile g has landed
@@ -454,17 +508,46 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
                 constexpr int KS = BK / 16;
                 bf16x8 fa[2][MI], fb[2][NI];
                 auto frags = [&](int ks, int buf) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * C::ROW + fo[ks]);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * C::ROW + fo[ks]);
-                    if constexpr (RELU) {                           // relu(cat(x, text)) of the fusion layer's Linear
+                    if constexpr (RC) {
+                        // MFMA operand (8 consecutive k of one row) out of the k-major image: two transposing reads of 4 k-rows
+                        const char* img = smem + slot * C::SLOT + ks * 16 * 256 + rc_row;
 #pragma unroll
                         for (int i = 0; i < MI; ++i) {
-                            ring_u32x4 w = __builtin_bit_cast(ring_u32x4, fa[buf][i]);
-                            w.x = ring_relu_bf16x2(w.x); w.y = ring_relu_bf16x2(w.y); w.z = ring_relu_bf16x2(w.z); w.w = ring_relu_bf16x2(w.w);
-                            fa[buf][i] = __builtin_bit_cast(bf16x8, w);
+                            const char* q = img + rc_a[i];
+                            const ring_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(q)));
+                            const ring_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(q + 4 * 256)));
+                            const ring_s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            fa[buf][i] = __builtin_bit_cast(bf16x8, r);
                         }
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const char* q = img + C::A_BYTES + rc_b[j];
+                            const ring_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(q)));
+                            const ring_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(q + 4 * 256)));
+                            const ring_s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            fb[buf][j] = __builtin_bit_cast(bf16x8, r);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * C::ROW + fo[ks]);
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * C::ROW + fo[ks]);
+                    }
+                    if constexpr (BGRAD) {                          // bias gradient = sum over k of A's rows (before any ReLU on A)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            const ring_u32x4 w = __builtin_bit_cast(ring_u32x4, fa[buf][i]);
+                            bsum[i] += ((ring_bf16lo(w.x) + ring_bf16hi(w.x)) + (ring_bf16lo(w.y) + ring_bf16hi(w.y))) +
+                                       ((ring_bf16lo(w.z) + ring_bf16hi(w.z)) + (ring_bf16lo(w.w) + ring_bf16hi(w.w)));
+                        }
+                    }
+                    if constexpr (RELU_A) {                         // e.g. relu(cat(x, text)) of the fusion layer's Linear
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) fa[buf][i] = relu8(fa[buf][i]);
+                    }
+                    if constexpr (RELU_B) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) fb[buf][j] = relu8(fb[buf][j]);
                     }
                 };
 #if defined(M2F_RING_EXP) && M2F_RING_EXP == 2      // experiment: no fragment reads / MFMAs (producer floor)
@@ -488,8 +571,31 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
         };
         const RingEpi E = ring_epilogue_args<BM, BN>(gb, P, m0, n0);
         M2F_TS(1);
-        if (reluA) kloop(std::true_type{});
-        else kloop(std::false_type{});
+        {
+            const std::true_type T1{}; const std::false_type F0{};
+            if constexpr (RC) {
+                const int sel = (reluA ? 1 : 0) | (reluB ? 2 : 0) | (bgrad ? 4 : 0);
+                switch (sel) {
+                    case 0: kloop(F0, F0, F0); break;  case 1: kloop(T1, F0, F0); break;
+                    case 2: kloop(F0, T1, F0); break;  case 3: kloop(T1, T1, F0); break;
+                    case 4: kloop(F0, F0, T1); break;  case 5: kloop(T1, F0, T1); break;
+                    case 6: kloop(F0, T1, T1); break;  default: kloop(T1, T1, T1); break;
+                }
+            } else {
+                if (reluA) kloop(T1, F0, F0);
+                else kloop(F0, F0, F0);
+            }
+        }
+        if constexpr (RC) {
+            if (bgrad) {                                            // lanes l and l + 32 hold the two k-halves of row l
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+                    if (lane < 32 && m < H.M) H.bias_grad[m] = tot;
+                }
+            }
+        }
         M2F_TS(3);
         ring_epilogue<MI, NI, BM, BN, TABLE>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
         M2F_TS(4);
@@ -497,17 +603,17 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
     ring_lds_barrier();                                                  // matches the producers' last barrier
 }
 
-template <int BM, int BN, int S, bool TABLE>
+template <int BM, int BN, int S, bool TABLE, bool RC = false>
 __global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
     const int total_tiles = gb.total_tiles, grid = (int)gridDim.x;
     const int first = ring_xcd_remap((int)blockIdx.x, grid);
-    if (threadIdx.x >= 256) ring_producer<BM, BN, S, TABLE>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
-    else ring_consumer<BM, BN, S, TABLE>(gb, smem, wave, lane, first, grid, total_tiles);
+    if (threadIdx.x >= 256) ring_producer<BM, BN, S, TABLE, RC>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
+    else ring_consumer<BM, BN, S, TABLE, RC>(gb, smem, wave, lane, first, grid, total_tiles);
 }
 
-template <int BM, int BN, int S, bool TABLE>
+template <int BM, int BN, int S, bool TABLE, bool RC = false>
 hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
     using C = RingCfg<BM, BN, S>;
     static int n_cu = 0;
@@ -516,7 +622,7 @@ hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    auto kern = m2f_gemm16_ring_kernel<BM, BN, S, TABLE>;
+    auto kern = m2f_gemm16_ring_kernel<BM, BN, S, TABLE, RC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);

@@ -115,7 +115,7 @@ hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream);
 #ifdef __cplusplus
 #include <vector>
-int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob);
+int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob, bool operand_options = false);
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -19,6 +19,10 @@
 #include "ops.h"
 #include "mega.h"
 
+#ifndef M2F_TABLE_TILE_DEFAULT
+#define M2F_TABLE_TILE_DEFAULT 130      // weight-gradient table launch: see build_plan (M2F_TABLE_TILE)
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -238,6 +242,7 @@ struct m2f_plan {
     // chain on a second stream was measured SLOWER inside the captured graph: every fork costs the chain a 12-16 us
     // cross-queue gap and the chain's small GEMMs run ~2x longer next to a chip-filling launch; 2.85 -> 2.77 ms/step.)
     std::vector<Launch> wg;
+    std::vector<Launch> wg_rest;     // weight gradients the table launch cannot take (row-major table form only)
     // bf16 mode: all weight gradients as ONE persistent k-contiguous GEMM launch over a device-resident problem table,
     // fed by token-transposed bf16 copies of dY / X made by one transposing launch (which also sums the bias gradients)
     bool wg_nt = false;
@@ -1092,7 +1097,49 @@ int build_plan(m2f_plan& P, char* ws_base) {
     const char* wg_env = getenv("M2F_WGRAD_TABLE");
     bool table_ok = P.train && !bld.wgrads.empty() && !(wg_env && wg_env[0] == '0');
     const int ldt = (T + 7) & ~7;
-    if (table_ok) {
+    // M2F_TABLE_TILE (read when a plan is built): 64 | 128 | 256 = register-staged builds of the table kernel on token-
+    // transposed operand copies (256 = 256x128 tiles); 129 = ring form (gemm_ring.h, 128x128 tiles) on the same copies;
+    // 130 = ring form on the ROW-MAJOR bf16 shadows the chain already maintains - no transposing launch, no copies, the
+    // kernel sums the bias gradients itself.
+    const char* tt_env = getenv("M2F_TABLE_TILE");
+    const int tt = tt_env ? atoi(tt_env) : 0;
+    const int table_tile = (tt == 64 || tt == 128 || tt == 129 || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
+    const bool table_rc = table_tile == 130;
+    if (table_ok && table_rc) {
+        // operands = shadows of the fp32 activations (same element index); every one of them is also the A operand of a
+        // forward-form chain launch, so its shadow is current when the backward chain has run
+        const float* wsf = reinterpret_cast<const float*>(ws_base);
+        auto shadow_ptr = [&](const float* ptr) -> const uint16_t* {
+            if (!ws_base) return reinterpret_cast<const uint16_t*>(16);           // sizing pass: any non-null, aligned value
+            const ptrdiff_t i = ptr - wsf;
+            return (i >= 0 && (size_t)i < ws_floats) ? shadow + i : nullptr;
+        };
+        std::vector<Op> rest_ops;
+        for (const GemmProblem& g : bld.wgrads) {
+            const uint16_t* qa = shadow_ptr(g.a.p[0]);
+            const uint16_t* qb = shadow_ptr(g.b.p[0]);
+            if (g.a.k[1] != 0 || g.b.k[1] != 0) { table_ok = false; break; }
+            if (!qa || !qb || (g.a.ld[0] & 7) || (g.b.ld[0] & 7) || (reinterpret_cast<uintptr_t>(qa) & 15) || (reinterpret_cast<uintptr_t>(qb) & 15) ||
+                (size_t)T * g.a.ld[0] * 2 >= 0x80000000ull || (size_t)T * g.b.ld[0] * 2 >= 0x80000000ull) {
+                // no 16-byte-stageable shadow (the [T, n_classes] criterion gradient): a grouped launch of its own
+                Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
+                o.gp.push_back(g);
+                rest_ops.push_back(o);
+                continue;
+            }
+            GemmProblem q;
+            memset(&q, 0, sizeof(q));
+            q.a.q[0] = qa; q.a.ldq[0] = g.a.ld[0]; q.a.k[0] = T;
+            q.b.q[0] = qb; q.b.ldq[0] = g.b.ld[0]; q.b.k[0] = T;
+            q.M = g.M; q.N = g.N; q.c = g.c; q.ldc = g.ldc; q.gate_scale = 1.f;
+            q.flags = g.flags & (uint32_t)(GF_RELU_A | GF_RELU_B);
+            q.bias_grad = g.bias_grad;
+            tprobs.push_back(q);
+            P.wg_flops += 2.0 * g.M * g.N * (double)T;
+        }
+        if (table_ok) to_launches(P, rest_ops, P.wg_rest);
+    }
+    if (table_ok && !table_rc) {
         auto item_of = [&](const float* src, int ld, int F, int relu) {
             for (size_t k = 0; k < titems.size(); ++k)
                 if (titems[k].src == src && titems[k].ld == ld && titems[k].F == F && titems[k].relu == relu) return (int)k;
@@ -1124,16 +1171,10 @@ int build_plan(m2f_plan& P, char* ws_base) {
         if (tblock.size() > 65535) table_ok = false;
     }
     int total_tiles = 0;
-    // 256x128 tiles (a quarter fewer operand bytes through L1 than 128x128: 145 vs 183 us at C2 once the staging ring kept its
-    // loads in flight).  M2F_TABLE_TILE=64|128 (read when a plan is built) selects the other register-staged builds of the table
-    // kernel, 129 the RING form with 128x128 tiles (gemm.hip, m2f_gemm16_ring_kernel).  The ring form's k-loop is ~2x faster per
-    // workgroup, but this launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together - bytes per
-    // FLOP decide, and the larger tile wins (C3 step 3.655 ms vs 3.707 with the ring form).  The tests run all of them against
-    // each other.
-    const char* tt_env = getenv("M2F_TABLE_TILE");
-    const int tt = tt_env ? atoi(tt_env) : 0;
-    const int table_tile = (tt == 64 || tt == 128 || tt == 129) ? tt : 256;
-    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, table_tile == 129 ? 128 : table_tile, tile_prob);
+    // Tile choice, measured: 256x128 register-staged tiles beat 128x128 ones on the transposed copies (a quarter fewer operand
+    // bytes through L1: 145 vs 183 us at C2) and also the ring form on the same copies (129: C3 step 3.707 vs 3.655 ms - this
+    // launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together, so bytes per FLOP decide).
+    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : table_tile, tile_prob, table_rc);
     if (total_tiles <= 0) table_ok = false;
     GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;
     uint16_t* d_tile_prob = table_ok ? bld.ar.alloc<uint16_t>(tile_prob.size()) : nullptr;
@@ -1143,8 +1184,10 @@ int build_plan(m2f_plan& P, char* ws_base) {
     if (table_ok && P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
         bool ok = hipMemcpy(d_table, tprobs.data(), tprobs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(d_tile_prob, tile_prob.data(), tile_prob.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemcpy(d_items, titems.data(), titems.size() * sizeof(TransItem), hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemcpy(d_tblock, tblock.data(), tblock.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+        if (!titems.empty()) {
+            ok = ok && hipMemcpy(d_items, titems.data(), titems.size() * sizeof(TransItem), hipMemcpyHostToDevice) == hipSuccess;
+            ok = ok && hipMemcpy(d_tblock, tblock.data(), tblock.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+        }
         if (ok) {
             P.wg_nt = true;
             P.wg_trans = {d_items, d_tblock, (int)tblock.size(), T};
@@ -1298,10 +1341,11 @@ int do_backward(m2f_plan& P, hipStream_t s) {
     } else if (int r = run_launches(P, P.bwd, s)) return r;
     if (P.wg_nt) {
         if (g_prof) g_prof->begin(10, 0.0);
-        M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
+        if (P.wg_trans.blocks > 0) M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
         if (g_prof) { g_prof->end(); g_prof->begin(M2F_LAYOUT_TN, P.wg_flops); }
         M2F_HIP(m2f_launch_gemm_table(P.wg_tab, s));
         if (g_prof) g_prof->end();
+        if (int r = run_launches(P, P.wg_rest, s)) return r;
     } else {
         if (int r = run_launches(P, P.wg, s)) return r;
     }
@@ -1434,7 +1478,7 @@ int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + plan->casts.size());
     if (phase == 1) return 2;
-    return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? 2 : plan->wg.size()) + plan->lnred.size());
+    return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() : plan->wg.size()) + plan->lnred.size());
 }
 
 static int do_forward(m2f_plan& P, hipStream_t s) {

@@ -209,11 +209,13 @@ def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monke
     assert checked >= 20
 
 
-@pytest.mark.parametrize("tile", ["64", "128", "129"])
+@pytest.mark.parametrize("tile", ["64", "128", "129", "256"])
 def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, tile, monkeypatch):
-    """The persistent weight-gradient table launch exists as register-staged 64x64, 128x128 and 256x128 (default) builds and
-    in the ring form (129: 128x128 tiles, LDS-direct staging) (M2F_TABLE_TILE, read when a plan is built): same operands and
-    k order, so the gradients agree to fp32 summation noise."""
+    """The weight-gradient table launch runs by default in the ring form on the row-major bf16 shadows (130: no token-
+    transposed copies; the kernel sums the bias gradients from the bf16 operands) and exists as register-staged 64x64,
+    128x128 and 256x128 builds and a ring form (129) on token-transposed copies, whose transposing launch sums the bias
+    gradients in fp32 (M2F_TABLE_TILE, read when a plan is built).  Same operands and k order for the weights: they agree
+    to fp32 summation noise; the bias gradients to the bf16 rounding of their summands."""
     fx = _load(golden_dir, "c2_slice")
     cfg, text, audio, key_pad, emotion = _inputs("c2_slice", fx)
     batch = (text, audio, key_pad, emotion)
@@ -221,10 +223,15 @@ def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, tile, monkey
     monkeypatch.setenv("M2F_TABLE_TILE", tile)
     g_variant = _train_grads(cfg, "bf16", batch)
     monkeypatch.delenv("M2F_TABLE_TILE")
+    checked_bias = 0
     for k, ref in g_default.items():
         scale = ref.abs().max().item()
         if scale >= 1e-6:
-            assert (g_variant[k] - ref).abs().max().item() <= 1e-4 * scale, k
+            summed_from_bf16 = ref.dim() == 1 and ("bias" in k)
+            tol = 4e-3 if summed_from_bf16 else 1e-4
+            assert (g_variant[k] - ref).abs().max().item() <= tol * scale, k
+            checked_bias += summed_from_bf16
+    assert checked_bias >= 10
 
 
 def test_live_oracle_full_size_properties():

@@ -265,7 +265,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
     }
     if roofline:
         out["roofline"] = {
-            "bound": "mfma", "kernel": "m2f_gemm16_dense_kernel / m2f_gemm16_table_kernel (bf16) or m2f_gemm_kernel (fp32): grouped MFMA GEMM, forward / dgrad / wgrad launches of one step"
+            "bound": "mfma", "kernel": "m2f_gemm16_ring_kernel (bf16: forward / input-gradient launches as 128x128, 128x64 or 64x64 ring tiles; the weight-gradient table launch in its row-major form) or m2f_gemm_kernel (fp32): grouped MFMA GEMM launches of one step"
                                        + (" [persistent kernels on: m2f_mega_kernel + m2f_gemm16_table_kernel]" if plan.persistent() else ""),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None if traffic is None or traffic["_stale"] else float(traffic["traffic_bytes_per_launch"]),

@@ -243,6 +243,7 @@ struct m2f_plan {
     // cross-queue gap and the chain's small GEMMs run ~2x longer next to a chip-filling launch; 2.85 -> 2.77 ms/step.)
     std::vector<Launch> wg;
     std::vector<Launch> wg_rest;     // weight gradients the table launch cannot take (row-major table form only)
+    std::vector<CastBatch> wg_casts;  // ... and the narrow operands it takes as padded bf16 copies made in front of it
     // bf16 mode: all weight gradients as ONE persistent k-contiguous GEMM launch over a device-resident problem table,
     // fed by token-transposed bf16 copies of dY / X made by one transposing launch (which also sums the bias gradients)
     bool wg_nt = false;
@@ -1115,12 +1116,24 @@ int build_plan(m2f_plan& P, char* ws_base) {
             return (i >= 0 && (size_t)i < ws_floats) ? shadow + i : nullptr;
         };
         std::vector<Op> rest_ops;
+        CastBatch wg_cast;
+        memset(&wg_cast, 0, sizeof(wg_cast));
         for (const GemmProblem& g : bld.wgrads) {
             const uint16_t* qa = shadow_ptr(g.a.p[0]);
             const uint16_t* qb = shadow_ptr(g.b.p[0]);
             if (g.a.k[1] != 0 || g.b.k[1] != 0) { table_ok = false; break; }
-            if (!qa || !qb || (g.a.ld[0] & 7) || (g.b.ld[0] & 7) || (reinterpret_cast<uintptr_t>(qa) & 15) || (reinterpret_cast<uintptr_t>(qb) & 15) ||
-                (size_t)T * g.a.ld[0] * 2 >= 0x80000000ull || (size_t)T * g.b.ld[0] * 2 >= 0x80000000ull) {
+            int lda = g.a.ld[0];
+            const bool b_ok = qb && !(g.b.ld[0] & 7) && !(reinterpret_cast<uintptr_t>(qb) & 15) && (size_t)T * g.b.ld[0] * 2 < 0x80000000ull;
+            if (b_ok && g.M <= 8 && !(g.flags & GF_RELU_A) && wg_cast.count < M2F_CAST_MAX_ITEMS) {
+                // a narrow dY without a 16-byte-stageable shadow (the [T, n_classes] criterion gradient): a bf16 copy with
+                // 8-column rows, made by a cast launch in front of the table launch (the pad column is zeroed once, here)
+                uint16_t* pad = bld.ar.alloc<uint16_t>((size_t)T * 8 + 128);      // + one 256-byte fragment row past the end
+                if (ws_base && hipMemset(pad, 0, ((size_t)T * 8 + 128) * sizeof(uint16_t)) != hipSuccess) { table_ok = false; break; }
+                CastItem& ci = wg_cast.it[wg_cast.count++];
+                ci.src = g.a.p[0]; ci.dst = pad; ci.rows = T; ci.cols = g.M; ci.lds = g.a.ld[0]; ci.ldd = 8; ci.dst_t = nullptr; ci.ldd_t = 0;
+                qa = pad; lda = 8;
+            }
+            if (!qa || !b_ok || (lda & 7) || (reinterpret_cast<uintptr_t>(qa) & 15) || (size_t)T * lda * 2 >= 0x80000000ull) {
                 // no 16-byte-stageable shadow (the [T, n_classes] criterion gradient): a grouped launch of its own
                 Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
                 o.gp.push_back(g);
@@ -1129,7 +1142,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
             }
             GemmProblem q;
             memset(&q, 0, sizeof(q));
-            q.a.q[0] = qa; q.a.ldq[0] = g.a.ld[0]; q.a.k[0] = T;
+            q.a.q[0] = qa; q.a.ldq[0] = lda; q.a.k[0] = T;
             q.b.q[0] = qb; q.b.ldq[0] = g.b.ld[0]; q.b.k[0] = T;
             q.M = g.M; q.N = g.N; q.c = g.c; q.ldc = g.ldc; q.gate_scale = 1.f;
             q.flags = g.flags & (uint32_t)(GF_RELU_A | GF_RELU_B);
@@ -1138,6 +1151,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
             P.wg_flops += 2.0 * g.M * g.N * (double)T;
         }
         if (table_ok) to_launches(P, rest_ops, P.wg_rest);
+        if (table_ok && wg_cast.count) P.wg_casts.push_back(wg_cast);
     }
     if (table_ok && !table_rc) {
         auto item_of = [&](const float* src, int ld, int F, int relu) {
@@ -1342,6 +1356,7 @@ int do_backward(m2f_plan& P, hipStream_t s) {
     if (P.wg_nt) {
         if (g_prof) g_prof->begin(10, 0.0);
         if (P.wg_trans.blocks > 0) M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
+        for (const CastBatch& cb : P.wg_casts) M2F_HIP(m2f_launch_cast(cb, s));
         if (g_prof) { g_prof->end(); g_prof->begin(M2F_LAYOUT_TN, P.wg_flops); }
         M2F_HIP(m2f_launch_gemm_table(P.wg_tab, s));
         if (g_prof) g_prof->end();
@@ -1478,7 +1493,7 @@ int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + plan->casts.size());
     if (phase == 1) return 2;
-    return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() : plan->wg.size()) + plan->lnred.size());
+    return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() + plan->wg_casts.size() : plan->wg.size()) + plan->lnred.size());
 }
 
 static int do_forward(m2f_plan& P, hipStream_t s) {

@@ -1281,7 +1281,11 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
         static const int ring_min = getenv("M2F_RING_MIN") ? atoi(getenv("M2F_RING_MIN")) : 200;
         static const int ring64_min = getenv("M2F_RING64_MIN") ? atoi(getenv("M2F_RING64_MIN")) : 150;
         static const int ring32_min = getenv("M2F_RING32_MIN") ? atoi(getenv("M2F_RING32_MIN")) : 80;
-        if (ring && auto_tile && m2f_gemm_ring_ok(gb)) {
+        // (launches of 1,024 and more 256x128 tiles - the in-loop text encoder at M = 32,768 - keep all CUs streaming for
+        // hundreds of microseconds and are bound by what the L2s pull together: the register-staged 256x128 build, 85 instead
+        // of 64 FLOP per byte, stays ahead there - RoBERTa-large geometry 52.3 vs 54.0 ms per forward; base geometry, whose
+        // launches stay below that size, 18.9 -> 17.9 ms with the ring form)
+        if (ring && auto_tile && tile != 256 && m2f_gemm_ring_ok(gb)) {
             if (count_tiles(128, 128) >= ring_min) return m2f_launch_gemm_ring(gb, 128, 128, stream);
             if (count_tiles(128, 64) >= ring64_min) return m2f_launch_gemm_ring(gb, 128, 64, stream);
             if (count_tiles(64, 64) >= ring32_min) return m2f_launch_gemm_ring(gb, 64, 64, stream);

@@ -12,7 +12,9 @@ for _ in range(5):
     F.gemm(a, b, F.NT, runtime.BF16, out=out, shadows=(a16, None, b16, None), tile=tile)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
-fn = runtime.lib().m2f_dbg_read
+# M2F_TIMING_RING=1: the stamps of the ring kernel (gemm_ring_128x128.hip keeps its own stamp array); pick a shape that takes the
+# 128x128 ring form (>= 200 tiles of 128x128, or M2F_RING_MIN=1)
+fn = runtime.lib().m2f_ring_dbg_read if os.environ.get("M2F_TIMING_RING") == "1" else runtime.lib().m2f_dbg_read
 fn.restype = ctypes.c_int
 assert fn(buf) == 0
 c = list(buf)

@@ -234,7 +234,12 @@ class _Engine:
 
 class M2FNet(nn.Module):
     """Drop-in for reference ``src/model.py:23-145``: ``M2FNet(config.model)``; ``forward(text, audio, mask)``
-    with text [B,L,d_t], audio [B,L,d_a] fp32 and mask bool [B,L] (True = pad) -> logits [B,L,output_size]."""
+    with text [B,L,d_t], audio [B,L,d_a] fp32 and mask bool [B,L] (True = pad) -> logits [B,L,output_size].
+
+    Limits the reference does not have: at most 64 utterances per dialogue (L <= 64: the dialogue attention kernels keep a
+    whole dialogue in one workgroup; MELD's longest dialogue has 33) - longer inputs raise from ``m2f_plan_create``; each
+    backward OVERWRITES the gradients (the reference zeroes them every step, ``src/train.py:227``), so accumulating over
+    several backward calls needs a caller-side buffer."""
 
     def __init__(self, config, precision: Optional[str] = None, shape_buckets: Optional[bool] = None):
         super().__init__()

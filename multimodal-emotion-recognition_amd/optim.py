@@ -51,6 +51,12 @@ class M2FCrossEntropyLoss(nn.Module):
 
 
 class FusedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` (coupled L2 weight decay, reference ``src/train.py:56``) as ONE kernel over the model's flat
+    parameter / gradient / moment buffers.  Differences from torch worth knowing: every parameter of the model is updated every
+    step - a parameter whose ``.grad`` is None is treated as having a zero gradient (it still receives weight decay and the
+    moment decay; torch skips it), which never happens on the M2FNet path, where backward writes every gradient; there is one
+    parameter group (one lr / betas / eps / weight_decay for the whole model)."""
+
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         self.model = model
         params = list(model.parameters())

@@ -244,7 +244,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         rocprof = {"source": kstats["_source"], "stale": kstats["_stale"]}
         if not kstats["_stale"]:
             rocprof.update({"avg_launch_us": kstats["avg_launch_us"], "gemm_ms_per_step": kstats["gemm_ms_per_step"],
-                            "achieved": kstats.get("gemm_gflop_per_step", gemm_fl / 1e9) / kstats["gemm_ms_per_step"] / 1e3})
+                            "achieved": kstats.get("gemm_gflop_per_step", gemm_fl / 1e9) / kstats["gemm_ms_per_step"], "unit": "TFLOP/s"})   # GFLOP / ms
     out = {
         "metric": "utterances/sec (fwd+bwd) M2FNet fusion, MELD dialogues, 1/2/4/8 MI355X",
         "value": utt_per_s, "unit": "utterances/s", "n_gpus": world, "steps": steps, "warmup": warmup,

@@ -209,15 +209,16 @@ def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monke
     assert checked >= 20
 
 
-@pytest.mark.parametrize("tile", ["64", "128", "129", "256"])
-def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, tile, monkeypatch):
+@pytest.mark.parametrize("name,tile", [("c2_slice", "64"), ("c2_slice", "128"), ("c2_slice", "129"), ("c2_slice", "256"),
+                                       ("tiny_ragged", "256"), ("tiny_shared_norm", "256"), ("tiny_no_fam", "129")])
+def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, name, tile, monkeypatch):
     """The weight-gradient table launch runs by default in the ring form on the row-major bf16 shadows (130: no token-
     transposed copies; the kernel sums the bias gradients from the bf16 operands) and exists as register-staged 64x64,
     128x128 and 256x128 builds and a ring form (129) on token-transposed copies, whose transposing launch sums the bias
     gradients in fp32 (M2F_TABLE_TILE, read when a plan is built).  Same operands and k order for the weights: they agree
     to fp32 summation noise; the bias gradients to the bf16 rounding of their summands."""
-    fx = _load(golden_dir, "c2_slice")
-    cfg, text, audio, key_pad, emotion = _inputs("c2_slice", fx)
+    fx = _load(golden_dir, name)
+    cfg, text, audio, key_pad, emotion = _inputs(name, fx)      # the tiny cases: widths below one tile, ragged token counts
     batch = (text, audio, key_pad, emotion)
     g_default = _train_grads(cfg, "bf16", batch)
     monkeypatch.setenv("M2F_TABLE_TILE", tile)
@@ -228,10 +229,10 @@ def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, tile, monkey
         scale = ref.abs().max().item()
         if scale >= 1e-6:
             summed_from_bf16 = ref.dim() == 1 and ("bias" in k)
-            tol = 4e-3 if summed_from_bf16 else 1e-4
+            tol = 8e-3 if summed_from_bf16 else 1e-4        # 2^-7: the summands are rounded to 8 significant bits
             assert (g_variant[k] - ref).abs().max().item() <= tol * scale, k
             checked_bias += summed_from_bf16
-    assert checked_bias >= 10
+    assert checked_bias >= (10 if name == "c2_slice" else 4)
 
 
 def test_live_oracle_full_size_properties():

@@ -61,3 +61,31 @@ __device__ __forceinline__ uint32_t m2f_fp8x4_bits(float a, float b, float c, fl
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);      // bytes 2, 3
     return (uint32_t)w;
 }
+
+#ifdef __HIPCC__
+// erf for the GELU epilogues.  POLY (bf16 / fp8 kernels): odd degree-13 minimax polynomial on |z| <= 3, max error 4.3e-4
+// (far inside bf16 operand rounding), 7 FMAs, no quarter-rate instructions; otherwise Abramowitz-Stegun 7.1.26 (1.5e-7) on
+// the hardware exp / rcp (libm's erff is several times slower still).
+template <bool POLY>
+__device__ __forceinline__ float m2f_gelu(float x) {
+    const float z = x * 0.70710678118654752f;
+    float e;
+    if constexpr (POLY) {
+        const float zc = fminf(fmaxf(z, -3.0f), 3.0f), t = zc * zc;
+        float p = 3.4737140595098026e-06f;
+        p = p * t - 0.0001298444258281961f;
+        p = p * t + 0.0020486447028815746f;
+        p = p * t - 0.018010087311267853f;
+        p = p * t + 0.098881796002388f;
+        p = p * t - 0.3658691942691803f;
+        p = p * t + 1.1261212825775146f;
+        e = fminf(fmaxf(p * zc, -1.0f), 1.0f);
+    } else {
+        const float az = fabsf(z);
+        const float tt = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+        const float poly = tt * (0.254829592f + tt * (-0.284496736f + tt * (1.421413741f + tt * (-1.453152027f + tt * 1.061405429f))));
+        e = copysignf(1.0f - poly * __expf(-az * az), z);
+    }
+    return 0.5f * x * (1.0f + e);
+}
+#endif

@@ -225,37 +225,13 @@ struct Stage {
     }
 };
 
+
 // Fused epilogue shared by the fp32-source and bf16-source kernels:
 //   +bias[n] -> relu -> dropout(site) -> +res[m,n] -> *(gate[m,n] > 0 ? gate_scale : 0) -> (C += | C =) [-> bf16 shadow of C]
 // Side loads are unconditional (clamped) and issued before the arithmetic; stores are predicated.
 // GELU is a COMPILE-TIME variant: carrying the erf expansion (and its constants) in every instantiation doubled the SGPR
 // spills of the chain kernels (24 -> 52) and cost the M2FNet step 3.4 %; only the text encoder's GEMMs use it.
-// erf for the GELU epilogues.  POLY (bf16 / fp8 kernels): odd degree-13 minimax polynomial on |z| <= 3, max error 4.3e-4
-// (far inside bf16 operand rounding), 7 FMAs, no quarter-rate instructions; otherwise Abramowitz-Stegun 7.1.26 (1.5e-7) on
-// the hardware exp / rcp (libm's erff is several times slower still).
-template <bool POLY>
-__device__ __forceinline__ float m2f_gelu(float x) {
-    const float z = x * 0.70710678118654752f;
-    float e;
-    if constexpr (POLY) {
-        const float zc = fminf(fmaxf(z, -3.0f), 3.0f), t = zc * zc;
-        float p = 3.4737140595098026e-06f;
-        p = p * t - 0.0001298444258281961f;
-        p = p * t + 0.0020486447028815746f;
-        p = p * t - 0.018010087311267853f;
-        p = p * t + 0.098881796002388f;
-        p = p * t - 0.3658691942691803f;
-        p = p * t + 1.1261212825775146f;
-        e = fminf(fmaxf(p * zc, -1.0f), 1.0f);
-    } else {
-        const float az = fabsf(z);
-        const float tt = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
-        const float poly = tt * (0.254829592f + tt * (-0.284496736f + tt * (1.421413741f + tt * (-1.453152027f + tt * 1.061405429f))));
-        e = copysignf(1.0f - poly * __expf(-az * az), z);
-    }
-    return 0.5f * x * (1.0f + e);
-}
-
+// (m2f_gelu: common.h)
 template <int MI, int NI, int BM, int BN, bool GELU = false, bool SCALE = false, bool GELU_POLY = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmBatch& gb, const GemmProblem& P, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn) {
@@ -1281,10 +1257,14 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
         static const int ring_min = getenv("M2F_RING_MIN") ? atoi(getenv("M2F_RING_MIN")) : 200;
         static const int ring64_min = getenv("M2F_RING64_MIN") ? atoi(getenv("M2F_RING64_MIN")) : 150;
         static const int ring32_min = getenv("M2F_RING32_MIN") ? atoi(getenv("M2F_RING32_MIN")) : 80;
-        // (launches of 1,024 and more 256x128 tiles - the in-loop text encoder at M = 32,768 - keep all CUs streaming for
-        // hundreds of microseconds and are bound by what the L2s pull together: the register-staged 256x128 build, 85 instead
-        // of 64 FLOP per byte, stays ahead there - RoBERTa-large geometry 52.3 vs 54.0 ms per forward; base geometry, whose
-        // launches stay below that size, 18.9 -> 17.9 ms with the ring form)
+        // Text-encoder-sized launches (M = utterances x tokens = 32,768): 256x128 ring tiles, whose k-loop runs at the MFMA rate
+        // (1,050 cycles per 256x128x64 k-tile against 1,024) and whose fixed cost per tile is amortised by the persistent walk.
+        // RoBERTa-large geometry 50.2 -> 43.4 ms per forward, base 17.4 -> 14.5 (threshold 512 tiles; 15.0 at 1,024; no
+        // launch of the M2FNet step is that large).
+        static const int ring256_min = getenv("M2F_RING256_MIN") ? atoi(getenv("M2F_RING256_MIN")) : 512;      // tiles of 256x128
+        if (ring && auto_tile && count_tiles(256, 128) >= ring256_min && m2f_gemm_ring256_ok(gb)) return m2f_launch_gemm_ring(gb, 256, 128, stream);
+        // (what the 256x128 ring form cannot take - it has bias / ReLU / GELU / residual epilogues only - keeps the register-staged
+        // 256x128 build from 1,024 such tiles on: RoBERTa-large geometry 52.3 vs 54.0 ms with 128x128 ring tiles)
         if (ring && auto_tile && tile != 256 && m2f_gemm_ring_ok(gb)) {
             if (count_tiles(128, 128) >= ring_min) return m2f_launch_gemm_ring(gb, 128, 128, stream);
             if (count_tiles(128, 64) >= ring64_min) return m2f_launch_gemm_ring(gb, 128, 64, stream);

@@ -57,7 +57,7 @@ __device__ __forceinline__ void ring_lds_barrier() {
 struct RingEpi {
     int M, N, ldc, ldres, ldgate;
     const float* bias; const float* res; const float* gate; float* C; uint16_t* C16;
-    float gscale; uint32_t site, key; bool relu_out, accum, vec;
+    float gscale; uint32_t site, key; bool relu_out, accum, vec, gelu;
 };
 template <int BM, int BN>
 __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const GemmProblem& P, int m0, int n0) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
     E.bias = P.bias; E.res = P.res; E.gate = P.gate; E.C = P.c;
     E.C16 = reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c));
     E.gscale = P.gate_scale;
-    E.relu_out = P.flags & GF_RELU_OUT; E.accum = P.flags & GF_ACCUM;
+    E.relu_out = P.flags & GF_RELU_OUT; E.accum = P.flags & GF_ACCUM; E.gelu = P.flags & GF_GELU_OUT;
     E.site = P.drop_site; E.key = 0;
     if (E.site) E.key = m2f_site_key(gb.rng, E.site);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -76,7 +76,10 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
     return E;
 }
 
-template <int MI, int NI, int BM, int BN, bool PLAIN = false>      // PLAIN: the launch form has no optional terms (weight-gradient table)
+// EPI selects the set of term combinations compiled in: 0 = all 16 (dropout site / gate / residual / accumulate), 1 = none
+// (the weight-gradient table), 2 = {-, residual} x {-, GELU} (the in-loop text encoder's launches: 256x128 tiles hold 128
+// accumulator registers, the full set would spill)
+template <int MI, int NI, int BM, int BN, int EPI = 0>
 __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi& E, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn, char* ep) {
     const int M = E.M, N = E.N;
@@ -97,6 +100,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
         constexpr int F = decltype(ftag)::value;
         float x = a + bv;
         x = relu_out ? fmaxf(x, 0.f) : x;
+        if constexpr (F & 16) x = m2f_gelu<true>(x);                 // (the polynomial erf of the bf16 kernels, gemm.hip)
         if constexpr (F & 1) x = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? x * gb.drop_scale : 0.f;
         if constexpr (F & 4) x = x + rv; else x = x + 0.f;
         if constexpr (F & 2) x = gv > 0.f ? x * gscale : 0.f;
@@ -105,6 +109,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
     auto element_rt = [&](float a, float bv, float rv, float gv, float cv, int row, int col) {      // edge tiles
         float x = a + bv;
         if (relu_out) x = fmaxf(x, 0.f);
+        if (EPI == 2 && E.gelu) x = m2f_gelu<true>(x);
         if (site) x = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? x * gb.drop_scale : 0.f;
         x = x + rv;
         if (gate) x = gv > 0.f ? x * gscale : 0.f;
@@ -180,9 +185,16 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                 if (b == 0) { M2F_TS(6); }
             }
         };
-        const int fmask = PLAIN ? 0 : (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0);
-        if constexpr (PLAIN) blocks(std::integral_constant<int, 0>{});
-        else switch (fmask) {
+        const int fmask = EPI == 1 ? 0 : (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0) | (E.gelu ? 16 : 0);
+        if constexpr (EPI == 1) blocks(std::integral_constant<int, 0>{});
+        else if constexpr (EPI == 2) {
+            switch (fmask) {                                        // (the launcher admits nothing else: m2f_gemm_ring_ok)
+                case 0: blocks(std::integral_constant<int, 0>{}); break;
+                case 4: blocks(std::integral_constant<int, 4>{}); break;
+                case 16: blocks(std::integral_constant<int, 16>{}); break;
+                default: blocks(std::integral_constant<int, 20>{}); break;
+            }
+        } else switch (fmask) {
 #define M2F_RING_EP(F) case F: blocks(std::integral_constant<int, F>{}); break;
             M2F_RING_EP(0) M2F_RING_EP(1) M2F_RING_EP(2) M2F_RING_EP(3) M2F_RING_EP(4) M2F_RING_EP(5) M2F_RING_EP(6) M2F_RING_EP(7)
             M2F_RING_EP(8) M2F_RING_EP(9) M2F_RING_EP(10) M2F_RING_EP(11) M2F_RING_EP(12) M2F_RING_EP(13) M2F_RING_EP(14) M2F_RING_EP(15)
@@ -447,7 +459,7 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     M2F_TS(5);
 }
 
-template <int BM, int BN, int S, bool TABLE, bool RC>
+template <int BM, int BN, int S, bool TABLE, bool RC, int EPI>
 __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, int wave, int lane, int first, int grid, int total_tiles) {
     using C = RingCfg<BM, BN, S>;
     constexpr int MI = BM / 64, NI = BN / 64, BK = C::BK;
@@ -597,23 +609,23 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
             }
         }
         M2F_TS(3);
-        ring_epilogue<MI, NI, BM, BN, TABLE>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
+        ring_epilogue<MI, NI, BM, BN, EPI>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
         M2F_TS(4);
     }
     ring_lds_barrier();                                                  // matches the producers' last barrier
 }
 
-template <int BM, int BN, int S, bool TABLE, bool RC = false>
+template <int BM, int BN, int S, bool TABLE, bool RC = false, int EPI = (TABLE ? 1 : 0)>
 __global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
     const int total_tiles = gb.total_tiles, grid = (int)gridDim.x;
     const int first = ring_xcd_remap((int)blockIdx.x, grid);
     if (threadIdx.x >= 256) ring_producer<BM, BN, S, TABLE, RC>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
-    else ring_consumer<BM, BN, S, TABLE, RC>(gb, smem, wave, lane, first, grid, total_tiles);
+    else ring_consumer<BM, BN, S, TABLE, RC, EPI>(gb, smem, wave, lane, first, grid, total_tiles);
 }
 
-template <int BM, int BN, int S, bool TABLE, bool RC = false>
+template <int BM, int BN, int S, bool TABLE, bool RC = false, int EPI = (TABLE ? 1 : 0)>
 hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
     using C = RingCfg<BM, BN, S>;
     static int n_cu = 0;
@@ -622,7 +634,7 @@ hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    auto kern = m2f_gemm16_ring_kernel<BM, BN, S, TABLE, RC>;
+    auto kern = m2f_gemm16_ring_kernel<BM, BN, S, TABLE, RC, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL);
@@ -635,7 +647,7 @@ hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
 }
 
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int EPI = 0>
 hipError_t launch_ring16(GemmBatch& gb, hipStream_t stream) {
     int t = 0;
     for (int i = 0; i < gb.count; ++i) {
@@ -659,7 +671,7 @@ hipError_t launch_ring16(GemmBatch& gb, hipStream_t stream) {
         h.flags = p.flags; h.tile_begin = p.tile_begin; h.has_bias_grad = 0;
     }
     hb.total_tiles = t;
-    return launch_ring_grid<BM, BN, S, false>(hb, t, stream);
+    return launch_ring_grid<BM, BN, S, false, false, EPI>(hb, t, stream);
 }
 
 }  // namespace

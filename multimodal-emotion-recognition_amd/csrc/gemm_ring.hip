@@ -1,5 +1,5 @@
 // RING form of the k-contiguous bf16 GEMM (gemm_ring.h): host-side dispatch over the tile configurations, each of which is
-// its own translation unit (gemm_ring_128x128.hip, gemm_ring_128x64.hip, gemm_ring_64x64.hip, gemm_ring_table.hip).
+// its own translation unit (gemm_ring_128x128.hip, gemm_ring_128x64.hip, gemm_ring_64x64.hip, gemm_ring_256x128.hip, gemm_ring_table.hip).
 #include "common.h"
 #include "ops.h"
 
@@ -10,6 +10,7 @@ extern "C" long long m2f_gemm_ring_launches(void) { return m2f_g_ring_launches; 
 hipError_t m2f_ring_launch_128x128(GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_128x64(GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_64x64(GemmBatch& gb, hipStream_t stream);
+hipError_t m2f_ring_launch_256x128(GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_table_128x128(const GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_table_rc_128x128(const GemmBatch& gb, hipStream_t stream);
 
@@ -26,10 +27,23 @@ bool m2f_gemm_ring_ok(const GemmBatch& gb) {
     return true;
 }
 
+// ... and as the 256x128 ring form, whose epilogue knows bias, ReLU, GELU and a residual only?
+bool m2f_gemm_ring256_ok(const GemmBatch& gb) {
+    for (int i = 0; i < gb.count; ++i) {
+        const GemmProblem& p = gb.pr[i];
+        if ((p.flags & (GF_RELU_B | GF_ACCUM)) || p.c8 || p.bias_grad || p.gate || p.drop_site) return false;
+        for (int sgm = 0; sgm < 2; ++sgm) {
+            if ((size_t)p.M * p.a.ldq[sgm] * 2 >= 0x80000000ull || (size_t)p.N * p.b.ldq[sgm] * 2 >= 0x80000000ull) return false;
+        }
+    }
+    return true;
+}
+
 hipError_t m2f_launch_gemm_ring(GemmBatch& gb, int bm, int bn, hipStream_t stream) {
     if (bm == 128 && bn == 128) return m2f_ring_launch_128x128(gb, stream);
     if (bm == 128 && bn == 64) return m2f_ring_launch_128x64(gb, stream);
     if (bm == 64 && bn == 64) return m2f_ring_launch_64x64(gb, stream);
+    if (bm == 256 && bn == 128) return m2f_ring_launch_256x128(gb, stream);          // needs m2f_gemm_ring256_ok
     return hipErrorInvalidValue;
 }
 

@@ -102,6 +102,7 @@ struct GemmBatch {
 
 // RING form of the k-contiguous bf16 GEMM (gemm_ring.h): bm x bn = 128x128 or 128x64; the table form walks gb.table.
 bool m2f_gemm_ring_ok(const GemmBatch& gb);
+bool m2f_gemm_ring256_ok(const GemmBatch& gb);       // 256x128 tiles: bias / ReLU / GELU / residual epilogues only
 hipError_t m2f_launch_gemm_ring(GemmBatch& gb, int bm, int bn, hipStream_t stream);
 hipError_t m2f_launch_gemm_ring_table(const GemmBatch& gb, hipStream_t stream);
 

@@ -149,7 +149,7 @@ LAUNCH_NAMES = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attn_fwd", "attn_bwd", 
 PARTS = ["encoders", "fusion", "classifier"]
 
 
-def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump=""):
+def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump="", packed=False):
     cfg, B, L = wl["cfg"], wl["B"], wl["L"]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=dtype).to(device).train()
@@ -158,7 +158,8 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
     text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device, ragged=ragged)
     n_valid = int((~mask).sum().item())                # utterances of this rank's batch (= B*L unless --ragged)
     eng = model.engine()
-    plan = eng.plan(B, L, True, True)
+    # --packed: token rows = valid utterances only (m2f_plan_create_packed); pays off with --ragged
+    plan = eng.plan(B, L, True, True, n_valid if packed else None)
 
     side = torch.cuda.Stream(device=device)
     with torch.cuda.stream(side):
@@ -230,7 +231,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         torch.distributed.all_reduce(nv)
     n_valid_all = int(nv.item())
     utt_per_s = n_valid_all / (elapsed / steps)
-    slots_per_s = world * B * L / (elapsed / steps)          # padded slots are computed too
+    slots_per_s = world * (plan.T if plan.packed else B * L) / (elapsed / steps)          # padded slots are computed too (unless packed)
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[dtype]
     wl_key = [k for k, v in WORKLOADS.items() if v is wl][0]
@@ -256,6 +257,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                    "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({stepper.reducer.exchange})" if world > 1 else "") + " + fused Adam",
                    "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                    "launches_per_step": plan.num_launches(), "persistent_kernels": plan.persistent(),
+                   "token_rows": plan.T, "packed": bool(plan.packed),
                    "source_hash": source_hash()},
         "loss": loss,
         "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": n_valid / fb_sec, "steps": n_fb,
@@ -300,6 +302,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="secondary workload of SURVEY 8-d: MELD-like dialogue lengths, "
                     "`value` then counts VALID utterances only")
+    ap.add_argument("--packed", action="store_true", help="packed token layout (valid utterances only; with --ragged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--buckets", type=int, default=4,
@@ -344,7 +347,7 @@ def main():
     use_graph = not args.no_graph
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
-                       roofline=True, dump=args.dump_launches if rank == 0 else "")
+                       roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed)
     if rank == 0:
         out = res
         if world == 1 and args.secondary != "none" and args.secondary != args.workload:

@@ -50,7 +50,8 @@ enum {
     M2F_BUF_LOSS = 6,       /* float [4]: loss, denominator, numerator, - ; for train plans this IS grads[total..] */
     M2F_BUF_DLOGITS = 7,    /* float [B*L, cls_out]  d loss / d logits (written by m2f_loss, or by host) */
     M2F_BUF_FAM0_OUT = 8,   /* float [B*L, pad8(d_fam)] first fusion layer output (kernel-level parity)  */
-    M2F_BUF_COUNT = 9
+    M2F_BUF_CU_SEQLENS = 9, /* int32 [B+1]           input of PACKED plans: dialogue b owns token rows cu[b] .. cu[b+1]-1 */
+    M2F_BUF_COUNT = 10
 };
 
 const char* m2f_last_error(void);
@@ -73,6 +74,15 @@ int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train);
 m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, int train,
                           float* params, float* grads, void* workspace, int64_t workspace_bytes,
                           uint32_t* rng_state);
+/* PACKED ("varlen") plan: the T token rows of every buffer belong to B dialogues of 1 .. L utterances each, dialogue b owning rows
+ * cu[b] .. cu[b+1]-1 of M2F_BUF_CU_SEQLENS (int32 [B+1], cu[0] = 0, cu[B] <= T, written by the caller before each step; rows from
+ * cu[B] on are padding: label -1, finite inputs).  No pad slots inside dialogues, so a ragged batch (reference collate_fn,
+ * src/dataset.py:69-89, pads every dialogue to the longest) costs its valid utterances only.  M2F_BUF_KEYPAD is not read.
+ * Same arithmetic per valid utterance as the padded plan of the same dialogues; B <= T <= B * L. */
+int64_t m2f_workspace_bytes_packed(const m2f_config* cfg, int B, int L, int T, int train);
+m2f_plan* m2f_plan_create_packed(const m2f_config* cfg, int B, int L, int T, int precision, int train,
+                                 float* params, float* grads, void* workspace, int64_t workspace_bytes,
+                                 uint32_t* rng_state);
 void m2f_plan_destroy(m2f_plan* plan);
 void* m2f_plan_buffer(m2f_plan* plan, int which);
 int m2f_plan_num_launches(m2f_plan* plan, int phase);   /* 0 fwd, 1 loss, 2 bwd */

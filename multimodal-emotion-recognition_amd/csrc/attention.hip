@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
     for (int i = 1; i < M2F_ATTN_MAX_PROBLEMS; ++i)
         if ((int)blockIdx.x >= ab.bb[i]) pi = i;
     const AttnProblem& P = ab.pr[pi];
-    const int H = P.H, hd = P.hd, L = ab.L;
+    const int H = P.H, hd = P.hd, LM = ab.L;                   // LM: the plan's utterances per dialogue (slab size, RNG index)
     const int bh = (int)blockIdx.x - P.block_begin;
     const int b = bh / H, h = bh - b * H;
     constexpr int Lp = 16 * NT;
@@ -133,11 +133,14 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
     float* Qs = sm;
     float* Ks = Qs + Lp * ld;
     float* Vs = Ks + Lp * ld;
-    const size_t tok0 = (size_t)b * L;
+    // padded layout: dialogue b owns rows b*LM .. +LM-1, pads flagged in key_pad; packed layout: rows cu[b] .. cu[b+1]-1, all valid
+    int L = LM;
+    size_t tok0 = (size_t)b * LM;
+    if (ab.cu) { const int c0 = ab.cu[b]; L = ab.cu[b + 1] - c0; tok0 = (size_t)c0; }
     const float* qg = P.q + tok0 * P.ldq + h * hd;
     const float* kg = P.k + tok0 * P.ldk + h * hd;
     const float* vg = P.v + tok0 * P.ldv + h * hd;
-    const unsigned char kpad = ab.key_pad[tok0 + (lane < L ? lane : 0)];
+    const unsigned char kpad = ab.cu ? (unsigned char)0 : ab.key_pad[tok0 + (lane < L ? lane : 0)];
     constexpr int NV = 2 * NT;                                // float4 per thread and slab: covers W <= 128
     if (slab_fast_ok<NV>(qg, P.ldq, hd, Lp, W) && slab_fast_ok<NV>(kg, P.ldk, hd, Lp, W) && slab_fast_ok<NV>(vg, P.ldv, hd, Lp, W)) {
         SlabGeom<NV> G;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
                 const int j = 16 * jt + 4 * lg + r;
                 float p = s[jt][r] * inv;
                 if (wv == 0) probs[(size_t)j * Lp + i] = p;  // P^T, pre-dropout (lanes: consecutive i); one wave writes it
-                if (site) p = m2f_keep(key, (uint32_t)((bh * L + i) * L + j), ab.drop_thresh) ? p * ab.drop_scale : 0.f;
+                if (site) p = m2f_keep(key, (uint32_t)((bh * LM + i) * LM + j), ab.drop_thresh) ? p * ab.drop_scale : 0.f;
                 s[jt][r] = p;
             }
         // O[i][c] = sum_j P[i][j] V[j][c]; the 16-column tiles are dealt to the four waves
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     for (int i = 1; i < M2F_ATTN_MAX_PROBLEMS; ++i)
         if ((int)blockIdx.x >= ab.bb[i]) pi = i;
     const AttnProblem& P = ab.pr[pi];
-    const int H = P.H, hd = P.hd, L = ab.L;
+    const int H = P.H, hd = P.hd, LM = ab.L;
     const int bh = (int)blockIdx.x - P.block_begin;
     const int b = bh / H, h = bh - b * H;
     constexpr int Lp = 16 * NT;
@@ -261,7 +264,9 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     float* Gs = Vs + Lp * ld;          // dO
     float* Os = Gs + Lp * ld;          // O (one-round-trip path only: present when ab.bwd_fast)
     float* delta = Os + (ab.bwd_fast ? Lp * ld : 0);       // [Lp]
-    const size_t tok0 = (size_t)b * L;
+    int L = LM;                                            // (packed layout: see the forward kernel)
+    size_t tok0 = (size_t)b * LM;
+    if (ab.cu) { const int c0 = ab.cu[b]; L = ab.cu[b + 1] - c0; tok0 = (size_t)c0; }
     const float* qg = P.q + tok0 * P.ldq + h * hd;
     const float* kg = P.k + tok0 * P.ldk + h * hd;
     const float* vg = P.v + tok0 * P.ldv + h * hd;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 const int j = 16 * jt + 4 * lg + r;
                 const float p = (NT == 1) ? px[r] : probs[(size_t)j * Lp + i];
                 float dp = acc[r];
-                if (site) dp = m2f_keep(key, (uint32_t)((bh * L + i) * L + j), ab.drop_thresh) ? dp * ab.drop_scale : 0.f;
+                if (site) dp = m2f_keep(key, (uint32_t)((bh * LM + i) * LM + j), ab.drop_thresh) ? dp * ab.drop_scale : 0.f;
                 ds[jt][r] = p * (dp - dl) * scale;
             }
         }
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 const int i = 16 * it + 4 * lg + r;
                 float p = p4[r], dp = acc[r], pdv = p;
                 if (site) {
-                    const bool kp = m2f_keep(key, (uint32_t)((bh * L + i) * L + j), ab.drop_thresh);
+                    const bool kp = m2f_keep(key, (uint32_t)((bh * LM + i) * LM + j), ab.drop_thresh);
                     dp = kp ? dp * ab.drop_scale : 0.f;
                     pdv = kp ? p * ab.drop_scale : 0.f;
                 }

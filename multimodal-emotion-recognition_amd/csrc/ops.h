@@ -142,6 +142,7 @@ struct AttnBatch {
     int count;
     int B, L;
     const uint8_t* key_pad;    // [B, L], 1 = padded key
+    const int* cu;             // PACKED layout (nullable): dialogue b owns token rows cu[b] .. cu[b+1]-1 (at most L of them); key_pad unused
     const uint32_t* rng;
     uint32_t drop_thresh;
     float drop_scale;

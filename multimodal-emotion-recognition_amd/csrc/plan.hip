@@ -226,6 +226,8 @@ struct m2f_plan {
     int B = 0, L = 0, T = 0, prec = 0, train = 0;
     float* params = nullptr;
     float* grads = nullptr;
+    bool packed = false;             // T token rows owned by B dialogues through cu_seqlens (m2f_plan_create_packed)
+    int* cu = nullptr;               // device int32 [B + 1] (packed plans)
     uint32_t* rng = nullptr;
     uint32_t drop_thresh = 0;
     float drop_scale = 1.f;
@@ -780,6 +782,7 @@ void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Laun
                 l.ab.count = (int)o.ap.size();
                 for (size_t i = 0; i < o.ap.size(); ++i) l.ab.pr[i] = o.ap[i];
                 l.ab.B = P.B; l.ab.L = P.L; l.ab.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
+                l.ab.cu = P.packed ? P.cu : nullptr;
                 l.ab.rng = P.rng; l.ab.drop_thresh = P.drop_thresh; l.ab.drop_scale = P.drop_scale;
                 break;
             case OP_LN_FWD: case OP_LN_BWD:
@@ -970,7 +973,8 @@ void mega_place(m2f_plan& P, Arena& ar, bool real, const MegaTables& mt, m2f_pla
 
 void build_mega(m2f_plan& P, Arena& ar, bool real) {
     const char* env = getenv("M2F_MEGA");
-    const bool want = M2F_MEGA_DEFAULT ? !(env && env[0] == '0') : (env && env[0] == '1');
+    // (packed plans keep the launch lists: the persistent kernels' strips assume whole dialogues of L rows)
+    const bool want = !P.packed && (M2F_MEGA_DEFAULT ? !(env && env[0] == '0') : (env && env[0] == '1'));
     const int NT = (P.L + 15) / 16, Lp = 16 * NT;
     int W = 16;
     for (const std::vector<Launch>* ls : {&P.fwd, &P.bwd})
@@ -1030,6 +1034,8 @@ int build_plan(m2f_plan& P, char* ws_base) {
     P.bufs[M2F_BUF_TEXT] = bld.ar.f((size_t)T * Builder::pad8(std::max(c.d_text, 1)));
     P.bufs[M2F_BUF_AUDIO] = bld.ar.f((size_t)T * Builder::pad8(std::max(c.d_audio, 1)));
     P.bufs[M2F_BUF_KEYPAD] = bld.ar.alloc<uint8_t>((size_t)T);
+    P.cu = bld.ar.alloc<int>((size_t)P.B + 1);
+    P.bufs[M2F_BUF_CU_SEQLENS] = P.cu;
     P.bufs[M2F_BUF_LABELS] = bld.ar.alloc<int64_t>((size_t)T);
     P.bufs[M2F_BUF_CLASSW] = bld.ar.f(16);
     if (c.audio_enabled)
@@ -1399,12 +1405,15 @@ int m2f_param_layout(const m2f_config* cfg, int64_t* offsets, int64_t* numels, i
     return n;
 }
 
-static m2f_plan* plan_new(const m2f_config* cfg, int B, int L, int precision, int train) {
+static m2f_plan* plan_new(const m2f_config* cfg, int B, int L, int precision, int train, int T_packed = 0) {
     if (B < 1 || L < 1 || L > 64) { fail("B >= 1 and 1 <= L <= 64 required (L = utterances per dialogue)"); return nullptr; }
+    if (T_packed < 0 || (T_packed > 0 && (T_packed < B || (int64_t)T_packed > (int64_t)B * L))) {
+        fail("packed plan: B <= T <= B * L token rows required"); return nullptr;
+    }
     if (precision != M2F_F32 && precision != M2F_BF16) { fail("bad precision"); return nullptr; }
     m2f_plan* p = new m2f_plan();
     p->cfg = *cfg;
-    p->B = B; p->L = L; p->T = B * L; p->prec = precision; p->train = train;
+    p->B = B; p->L = L; p->T = T_packed > 0 ? T_packed : B * L; p->packed = T_packed > 0; p->prec = precision; p->train = train;
     if (build_param_map(*cfg, p->pm)) { delete p; return nullptr; }
     if ((cfg->audio_enabled && (cfg->nlayers_audio < 1 || cfg->ntrans_audio < 1)) ||
         (cfg->text_enabled && (cfg->nlayers_text < 1 || cfg->ntrans_text < 1)) ||
@@ -1421,8 +1430,14 @@ static m2f_plan* plan_new(const m2f_config* cfg, int B, int L, int precision, in
     return p;
 }
 
-int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train) {
-    m2f_plan* p = plan_new(cfg, B, L, M2F_F32, train);
+static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int train, int T_packed);
+int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train) { return workspace_bytes_impl(cfg, B, L, train, 0); }
+int64_t m2f_workspace_bytes_packed(const m2f_config* cfg, int B, int L, int T, int train) {
+    if (T < 1) { fail("packed plan: T >= 1 required"); return -1; }
+    return workspace_bytes_impl(cfg, B, L, train, T);
+}
+static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int train, int T_packed) {
+    m2f_plan* p = plan_new(cfg, B, L, M2F_F32, train, T_packed);
     if (!p) return -1;
     p->params = nullptr; p->grads = nullptr;
     build_plan(*p, nullptr);
@@ -1431,9 +1446,20 @@ int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train) {
     return n;
 }
 
+static m2f_plan* plan_create_impl(const m2f_config* cfg, int B, int L, int T_packed, int precision, int train, float* params,
+                                  float* grads, void* workspace, int64_t workspace_bytes, uint32_t* rng_state);
 m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, int train, float* params, float* grads,
                           void* workspace, int64_t workspace_bytes, uint32_t* rng_state) {
-    m2f_plan* p = plan_new(cfg, B, L, precision, train);
+    return plan_create_impl(cfg, B, L, 0, precision, train, params, grads, workspace, workspace_bytes, rng_state);
+}
+m2f_plan* m2f_plan_create_packed(const m2f_config* cfg, int B, int L, int T, int precision, int train, float* params, float* grads,
+                                 void* workspace, int64_t workspace_bytes, uint32_t* rng_state) {
+    if (T < 1) { fail("packed plan: T >= 1 required"); return nullptr; }
+    return plan_create_impl(cfg, B, L, T, precision, train, params, grads, workspace, workspace_bytes, rng_state);
+}
+static m2f_plan* plan_create_impl(const m2f_config* cfg, int B, int L, int T_packed, int precision, int train, float* params,
+                                  float* grads, void* workspace, int64_t workspace_bytes, uint32_t* rng_state) {
+    m2f_plan* p = plan_new(cfg, B, L, precision, train, T_packed);
     if (!p) return nullptr;
     if (!params || !workspace) { fail("params / workspace must not be NULL"); delete p; return nullptr; }
     if (train && !grads) { fail("train plan needs a gradient buffer"); delete p; return nullptr; }
@@ -1444,7 +1470,7 @@ m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, in
     }
     p->params = params; p->grads = grads; p->rng = rng_state;
     {   // size the workspace with a dry build BEFORE anything is written into it
-        const int64_t need = m2f_workspace_bytes(cfg, B, L, train);
+        const int64_t need = workspace_bytes_impl(cfg, B, L, train, T_packed);
         if (need < 0 || need > workspace_bytes) {
             fail("workspace too small: need " + std::to_string(need) + " bytes");
             delete p;

@@ -122,9 +122,7 @@ class _Anchor(torch.autograd.Function):
         if plan.version != ctx.version:
             raise RuntimeError("M2FNet: the activations of this forward were overwritten by a later forward of the "
                                "same (B, L) shape; call backward() before the next forward()")
-        if plan.dlogits.shape != plan._dlogits.shape:
-            plan._dlogits.zero_()                 # filler slots of a bucketed plan carry no gradient
-        plan.dlogits.copy_(dlogits.reshape(plan.dlogits.shape))
+        plan.set_dlogits(dlogits)
         plan.backward()
         ctx.model._engine.publish_grads()
         return None, None, None
@@ -185,10 +183,20 @@ class _Engine:
         Bb = 1 << max(B - 1, 0).bit_length() if B <= 8 else (B + 7) // 8 * 8
         return Bb, Lb
 
-    def plan(self, B: int, L: int, want_backward: bool, dropout_active: bool) -> runtime.Plan:
+    def plan(self, B: int, L: int, want_backward: bool, dropout_active: bool, valid: Optional[int] = None) -> runtime.Plan:
+        """valid: number of valid utterances of the batch (packed mode) - the plan then holds that many token rows (rounded up to
+        a multiple of 64, plus one row per filler dialogue and one spare) instead of B x L slots; batches that are at least
+        85 % full keep the padded plan."""
+        b_in = B
         if self.shape_buckets:
             B, L = self.bucket(B, L)
-        key = (B, L, want_backward, dropout_active, self.precision)
+        T = None
+        if valid is not None:
+            need = int(valid) + (B - b_in) + 1
+            Tb = (need + 63) // 64 * 64
+            if Tb <= 0.85 * B * L:
+                T = max(Tb, B)
+        key = (B, L, T, want_backward, dropout_active, self.precision)
         pl = self.plans.get(key)
         if pl is None:
             cfg = self.cfg
@@ -199,7 +207,7 @@ class _Engine:
             if train:
                 self.ensure_grad()
             self._evict(max(self.max_plans, 1) - 1)
-            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng)
+            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng, T=T)
             self.plans[key] = pl
         else:
             self.plans.move_to_end(key)
@@ -241,9 +249,14 @@ class M2FNet(nn.Module):
     backward OVERWRITES the gradients (the reference zeroes them every step, ``src/train.py:227``), so accumulating over
     several backward calls needs a caller-side buffer."""
 
-    def __init__(self, config, precision: Optional[str] = None, shape_buckets: Optional[bool] = None):
+    def __init__(self, config, precision: Optional[str] = None, shape_buckets: Optional[bool] = None,
+                 packed: Optional[bool] = None):
         super().__init__()
         self.config = config
+        # packed ("varlen") token layout for `train_step` and no-grad `forward` (runtime.Plan, m2f_plan_create_packed): a ragged
+        # batch costs its valid utterances, not B x L slots; needs the batch's valid count on the host (one sync per call).
+        # Off by default (M2F_PACKED=1 or packed=True): the reference's batches reach the model as padded tensors either way
+        self.packed = (os.environ.get("M2F_PACKED", "0") == "1") if packed is None else bool(packed)
         # round batch shapes up to a few plan shapes (see _Engine.bucket); M2F_SHAPE_BUCKETS=0 plans every shape exactly
         self.shape_buckets = (os.environ.get("M2F_SHAPE_BUCKETS", "1") != "0") if shape_buckets is None else bool(shape_buckets)
         c = M2FConfig.from_model_config(config)           # raises the reference's two ValueErrors
@@ -305,7 +318,8 @@ class M2FNet(nn.Module):
         eng = self.engine(mask.device)
         B, L = mask.shape
         want_bwd = torch.is_grad_enabled() and any(p.requires_grad for p, *_ in eng.items)
-        plan = eng.plan(B, L, want_bwd, self.training and self.m2f_config.dropout > 0.0)
+        valid = int((~mask.bool()).sum()) if self.packed else None
+        plan = eng.plan(B, L, want_bwd, self.training and self.m2f_config.dropout > 0.0, valid)
         plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask)
         if want_bwd:
             return _Anchor.apply(eng.anchor, self, plan)
@@ -321,7 +335,8 @@ class M2FNet(nn.Module):
         the gradients in ``p.grad`` (views of the flat buffer)."""
         eng = self.engine(mask.device)
         B, L = mask.shape
-        plan = eng.plan(B, L, True, self.training and self.m2f_config.dropout > 0.0)
+        valid = int((~mask.bool()).sum()) if self.packed else None
+        plan = eng.plan(B, L, True, self.training and self.m2f_config.dropout > 0.0, valid)
 
         def body():
             plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask, emotion)

@@ -24,7 +24,7 @@ HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "include", "m2fnet_hip.h
 F32, BF16 = 0, 1
 PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
 (BUF_TEXT, BUF_AUDIO, BUF_KEYPAD, BUF_LABELS, BUF_CLASSW, BUF_LOGITS, BUF_LOSS, BUF_DLOGITS,
- BUF_FAM0_OUT) = range(9)
+ BUF_FAM0_OUT, BUF_CU_SEQLENS) = range(10)
 
 c_void_p, c_int, c_float, c_int64, c_uint32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                 ctypes.c_int64, ctypes.c_uint32)
@@ -56,8 +56,11 @@ SIGNATURES = {
     "m2f_param_layout": (c_int, [ctypes.POINTER(M2FConfigC), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int,
                                  ctypes.POINTER(c_int64)]),
     "m2f_workspace_bytes": (c_int64, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int]),
+    "m2f_workspace_bytes_packed": (c_int64, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int]),
     "m2f_plan_create": (c_void_p, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_void_p]),
+    "m2f_plan_create_packed": (c_void_p, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_void_p]),
     "m2f_plan_destroy": (None, [c_void_p]),
     "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
     "m2f_plan_num_launches": (c_int, [c_void_p, c_int]),
@@ -177,12 +180,16 @@ class Plan:
     """One bound launch list (config, B, L, precision, train/eval) + its workspace."""
 
     def __init__(self, cfg: M2FConfig, B: int, L: int, precision: int, train: bool, params: torch.Tensor,
-                 grads: Optional[torch.Tensor], rng_state: Optional[torch.Tensor]):
+                 grads: Optional[torch.Tensor], rng_state: Optional[torch.Tensor], T: Optional[int] = None):
+        """T: PACKED plan (m2f_plan_create_packed) - T token rows shared by the B dialogues through cu_seqlens; `set_inputs`
+        packs the padded batch it is given and `logits` unpacks, so callers see the padded [B, L, ...] surface either way."""
         require_gpu()
-        self.cfg, self.B, self.L, self.T = cfg, B, L, B * L
+        self.packed = T is not None
+        self.cfg, self.B, self.L, self.T = cfg, B, L, (int(T) if self.packed else B * L)
         self.precision, self.train = precision, train
         self._cc = config_to_c(cfg)
-        nbytes = lib().m2f_workspace_bytes(ctypes.byref(self._cc), B, L, int(train))
+        nbytes = (lib().m2f_workspace_bytes_packed(ctypes.byref(self._cc), B, L, self.T, int(train)) if self.packed
+                  else lib().m2f_workspace_bytes(ctypes.byref(self._cc), B, L, int(train)))
         if nbytes < 0:
             raise HipError(lib().m2f_last_error().decode())
         self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=params.device)
@@ -192,8 +199,12 @@ class Plan:
         base = self.workspace.data_ptr()
         self._ws_off = (-base) % 256
         self._keep = (params, grads, rng_state)
-        self.handle = lib().m2f_plan_create(ctypes.byref(self._cc), B, L, precision, int(train), params.data_ptr(),
-                                            ptr(grads), base + self._ws_off, nbytes, ptr(rng_state))
+        if self.packed:
+            self.handle = lib().m2f_plan_create_packed(ctypes.byref(self._cc), B, L, self.T, precision, int(train),
+                                                       params.data_ptr(), ptr(grads), base + self._ws_off, nbytes, ptr(rng_state))
+        else:
+            self.handle = lib().m2f_plan_create(ctypes.byref(self._cc), B, L, precision, int(train), params.data_ptr(),
+                                                ptr(grads), base + self._ws_off, nbytes, ptr(rng_state))
         if not self.handle:
             raise HipError("m2f_plan_create: " + lib().m2f_last_error().decode())
         C = cfg.cls_out
@@ -203,7 +214,9 @@ class Plan:
         self.keypad_in = self._view(BUF_KEYPAD, (self.T,), torch.uint8)
         self.labels_in = self._view(BUF_LABELS, (self.T,), torch.int64)
         self.class_w = self._view(BUF_CLASSW, (16,), torch.float32)
-        self._logits = self._view(BUF_LOGITS, (B, L, C), torch.float32)
+        self._logits = self._view(BUF_LOGITS, (self.T, C) if self.packed else (B, L, C), torch.float32)
+        self.cu_in = self._view(BUF_CU_SEQLENS, (B + 1,), torch.int32)
+        self._dst = self._valid = None        # packed plans: token row of every (dialogue, slot) of the last batch; its validity
         if train and grads is not None:
             # (loss, den, num) live in the tail of the flat gradient buffer (see include/m2fnet_hip.h)
             assert grads.numel() >= params.numel() + 4, "gradient buffer needs a 64-float tail"
@@ -211,25 +224,35 @@ class Plan:
             assert self.loss.data_ptr() == lib().m2f_plan_buffer(self.handle, BUF_LOSS)
         else:
             self.loss = self._view(BUF_LOSS, (4,), torch.float32)
-        self._dlogits = self._view(BUF_DLOGITS, (B, L, C), torch.float32)
-        self._fam0_out = (self._view(BUF_FAM0_OUT, (B, L, pad8(cfg.d_fam)), torch.float32)[..., : cfg.d_fam]
-                          if cfg.fam_enabled else None)
+        self._dlogits = self._view(BUF_DLOGITS, (self.T, C) if self.packed else (B, L, C), torch.float32)
+        self._fam0_out = (self._view(BUF_FAM0_OUT, (self.T, pad8(cfg.d_fam)) if self.packed else (B, L, pad8(cfg.d_fam)),
+                                     torch.float32)[..., : cfg.d_fam] if cfg.fam_enabled else None)
         # shape of the batch last handed to set_inputs: a plan may be larger than the batch it runs (shape buckets), the
         # result views below are cut to the batch
         self.in_B, self.in_L = B, L
         self.version = 0          # bumped by every forward; backward checks it still owns the activations
 
+    def _unpack(self, rows: torch.Tensor) -> torch.Tensor:
+        """[T, C] rows of a packed plan -> the padded [b, l, C] surface of the last batch (pad slots = 0)."""
+        return rows[self._dst] * self._valid[..., None].to(rows.dtype)
+
     @property
     def logits(self) -> torch.Tensor:
+        if self.packed:
+            return self._unpack(self._logits)
         return self._logits[: self.in_B, : self.in_L]
 
     @property
     def dlogits(self) -> torch.Tensor:
+        if self.packed:
+            return self._unpack(self._dlogits)
         return self._dlogits[: self.in_B, : self.in_L]
 
     @property
     def fam0_out(self) -> Optional[torch.Tensor]:
-        return None if self._fam0_out is None else self._fam0_out[: self.in_B, : self.in_L]
+        if self._fam0_out is None:
+            return None
+        return self._unpack(self._fam0_out) if self.packed else self._fam0_out[: self.in_B, : self.in_L]
 
     def _view(self, which: int, shape, dtype) -> torch.Tensor:
         p = lib().m2f_plan_buffer(self.handle, which)
@@ -268,6 +291,8 @@ class Plan:
         if b > self.B or l > self.L:
             raise HipError(f"batch {b} x {l} does not fit the plan {self.B} x {self.L}")
         self.in_B, self.in_L = b, l
+        if self.packed:
+            return self._set_inputs_packed(text, audio, key_pad.reshape(b, l), labels)
         if (b, l) == (self.B, self.L):
             if text is not None and self.cfg.text_enabled:
                 self.text_in.copy_(text.reshape(self.T, -1), non_blocking=True)
@@ -292,6 +317,46 @@ class Plan:
         self.labels_in.fill_(-1)
         if labels is not None:
             self.labels_in.view(B, L)[:b, :l].copy_(labels, non_blocking=True)
+
+    def _set_inputs_packed(self, text, audio, key_pad, labels) -> None:
+        """Packs a padded batch: the valid slots of dialogue b (in order) become token rows cu[b] .. cu[b+1]-1, no sync with
+        the host.  Filler dialogues of a bucketed plan get one zero, unlabeled row each; row T-1 absorbs the scatter of the
+        pad slots and is zeroed afterwards (the engine sizes T for valid + fillers + 1 rows).  Rows past the last dialogue are
+        padding: zero features, label -1 - they contribute exact zeros to the loss and to every gradient."""
+        b, l = key_pad.shape
+        dev, T = key_pad.device, self.T
+        valid = ~key_pad.bool()
+        rank = torch.cumsum(valid, 1, dtype=torch.int64) - 1                     # position among the dialogue's valid slots
+        lens = valid.sum(1, dtype=torch.int64)
+        cu = torch.zeros(self.B + 1, dtype=torch.int64, device=dev)
+        cu[1: b + 1] = torch.cumsum(lens, 0)
+        if b < self.B:
+            cu[b + 1:] = cu[b] + torch.arange(1, self.B - b + 1, device=dev)
+        self.cu_in.copy_(cu.to(torch.int32), non_blocking=True)
+        dst = torch.where(valid, cu[:b, None] + rank, torch.full_like(rank, T - 1))
+        self._dst, self._valid = dst, valid
+        flat = dst.reshape(-1)
+        for buf, src, on in ((self.text_in, text, self.cfg.text_enabled), (self.audio_in, audio, self.cfg.audio_enabled)):
+            if src is not None and on:
+                buf.zero_()
+                buf.index_copy_(0, flat, src.reshape(b * l, -1).to(buf.dtype))
+                buf[T - 1].zero_()
+        self.keypad_in.zero_()
+        self.labels_in.fill_(-1)
+        if labels is not None:
+            self.labels_in.index_copy_(0, flat, labels.reshape(-1).to(torch.int64))
+            self.labels_in[T - 1] = -1
+
+    def set_dlogits(self, g: torch.Tensor) -> None:
+        """d loss / d logits of the last batch ([b, l, C], padded surface) into the plan's buffer."""
+        if self.packed:
+            self._dlogits.zero_()
+            self._dlogits.index_copy_(0, self._dst.reshape(-1), (g * self._valid[..., None].to(g.dtype)).reshape(-1, g.shape[-1]))
+            self._dlogits[self.T - 1].zero_()
+            return
+        if self.in_B != self.B or self.in_L != self.L:
+            self._dlogits.zero_()                 # filler slots of a bucketed plan carry no gradient
+        self._dlogits[: self.in_B, : self.in_L].copy_(g.reshape(self.in_B, self.in_L, -1))
 
     def forward(self) -> torch.Tensor:
         self.version += 1

@@ -242,8 +242,10 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
 //     prefetch the fragments of k-slice s+1 while the MFMAs of slice s run;
 //   * one workgroup barrier per k-tile; the producers run S - 1 k-tiles ahead ACROSS output tiles, so the next tile's
 //     first operands arrive under the epilogue of the current one (persistent tile loop, grid <= number of CUs).
-// Same accumulation order per output element as gemm16_body (k ascending, one MFMA chain) and the same epilogue code,
-// so the results are bit-identical to the 64x64 / 128x128 builds.
+// Same accumulation order per output element as gemm16_body (k ascending, one MFMA chain) and the same epilogue operations per
+// element (ring_epilogue), so the results are bit-identical to the register-staged builds (tests/test_gemm_ring_gpu.py).
+// Tile configurations: 128x128 / 128x64 / 64x64 (4-5 slots) for the M2FNet step by launch size, 256x128 (3 slots) for
+// text-encoder-sized launches, and the table forms of the weight-gradient launch (TABLE; RC = row-major operands).
 // =========================================================================================================
 typedef __amdgpu_buffer_rsrc_t m2f_rsrc_t;
 template <int BM, int BN, int S>

@@ -242,6 +242,16 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
             }
         }
     }
+    // packed layout: the token rows behind the last dialogue (cu[B] .. T-1) belong to nobody; a plan is re-used for batches of
+    // other lengths, so they are written (zeros) by the last dialogue's workgroups - head h its own columns
+    if (ab.cu && b == ab.B - 1) {
+        for (int r = ab.cu[ab.B] + wv; r < ab.T; r += NWAVE)
+            for (int c = lane; c < hd; c += 64) {
+                const size_t idx = (size_t)r * P.ldo + h * hd + c;
+                P.out[idx] = 0.f;
+                if (out16) out16[idx] = 0;
+            }
+    }
 }
 
 template <int NT>
@@ -440,6 +450,18 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 }
             }
         }
+    }
+    // packed layout: zero gradients for the token rows behind the last dialogue (see the forward kernel) - the input-gradient
+    // and weight-gradient GEMMs read every row of these buffers
+    if (ab.cu && b == ab.B - 1) {
+        for (int r = ab.cu[ab.B] + wv; r < ab.T; r += NWAVE)
+            for (int c = lane; c < hd; c += 64) {
+                const size_t iq = (size_t)r * P.lddq + h * hd + c, ik = (size_t)r * P.lddk + h * hd + c, iv = (size_t)r * P.lddv + h * hd + c;
+                P.dq[iq] = 0.f; P.dk[ik] = 0.f; P.dv[iv] = 0.f;
+                if (dq16) dq16[iq] = 0;
+                if (dk16) dk16[ik] = 0;
+                if (dv16) dv16[iv] = 0;
+            }
     }
 }
 

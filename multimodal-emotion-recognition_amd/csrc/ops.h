@@ -143,6 +143,7 @@ struct AttnBatch {
     int B, L;
     const uint8_t* key_pad;    // [B, L], 1 = padded key
     const int* cu;             // PACKED layout (nullable): dialogue b owns token rows cu[b] .. cu[b+1]-1 (at most L of them); key_pad unused
+    int T;                     // PACKED layout: token rows of the buffers; rows cu[B] .. T-1 belong to no dialogue and are written as zeros
     const uint32_t* rng;
     uint32_t drop_thresh;
     float drop_scale;

@@ -782,7 +782,7 @@ void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Laun
                 l.ab.count = (int)o.ap.size();
                 for (size_t i = 0; i < o.ap.size(); ++i) l.ab.pr[i] = o.ap[i];
                 l.ab.B = P.B; l.ab.L = P.L; l.ab.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
-                l.ab.cu = P.packed ? P.cu : nullptr;
+                l.ab.cu = P.packed ? P.cu : nullptr; l.ab.T = P.T;
                 l.ab.rng = P.rng; l.ab.drop_thresh = P.drop_thresh; l.ab.drop_scale = P.drop_scale;
                 break;
             case OP_LN_FWD: case OP_LN_BWD:

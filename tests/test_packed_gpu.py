@@ -65,6 +65,29 @@ def test_packed_plan_equals_padded_plan(name, precision):
     assert torch.equal(l2, l3) and abs(l2.item() - l1.item()) <= 1e-6 * max(1.0, abs(l1.item()))
 
 
+def test_packed_plan_is_reused_for_batches_of_other_lengths():
+    """One packed plan (same B, L, T bucket) serves batches whose dialogues have other lengths: nothing of the previous batch
+    may leak through the token rows that belong to no dialogue (they are rewritten as zeros every step)."""
+    cfg, B, L, _ = _ragged_case("two_tiles")
+    cfg = dict(cfg, dropout=0.0)
+    sd = synth.make_state_dict(cfg)
+    ref, new = _model(cfg, sd, "bf16", False), _model(cfg, sd, "bf16", True)
+    seen = set()
+    for step, lengths in enumerate([[24, 20, 6, 20, 20, 15, 8], [24, 15, 23, 9, 15, 15, 5], [24, 1, 1, 2, 24, 24, 24], [24, 20, 6, 20, 20, 15, 8]]):
+        text, audio, key_pad, emotion = [t.cuda() for t in synth.make_inputs(cfg, B, L, lengths, "randn", seed=step)]
+        l0 = ref.train_step(text, audio, key_pad, emotion, use_graph=step > 0)
+        l1 = new.train_step(text, audio, key_pad, emotion, use_graph=step > 0)
+        torch.cuda.synchronize()
+        eng = new.engine()
+        plan = eng.plans[next(reversed(eng.plans))]
+        assert plan.packed
+        seen.add(plan.T)
+        assert abs(l0.item() - l1.item()) <= 2e-6 * max(1.0, abs(l0.item()))
+        g0, g1 = ref.engine().flat_grad, eng.flat_grad
+        assert (g0 - g1).abs().max().item() <= 2e-4 * g0.abs().max().item(), (step, (g0 - g1).abs().max().item())
+    assert len(new.engine().plans) == len(seen) <= 2          # the plans really were re-used
+
+
 def test_packed_inference_and_autograd_surface():
     """no-grad forward through a packed plan == padded forward at the valid slots; the autograd surface (loss.backward() on
     the returned logits) scatters d logits into the packed buffer."""

@@ -50,6 +50,7 @@ WORKLOADS = {
                name="C2 M2FNet full (6 enc layers/modality, 5 FAM) roberta-base 768 + audio_mel 300, B32xL16"),
     "c2p": dict(cfg=model_cfg(768, 768, 768, 8, 8, 8, 6, 5), B=32, L=16, name="C2' shipped config.yaml 768/768/768 B32xL16"),
     "c3": dict(cfg=model_cfg(768, 1024, 768, 8, 8, 8, 6, 5), B=64, L=16, name="C3 roberta-large 1024 + wav2vec2 768, B64xL16"),
+    "c3b256": dict(cfg=model_cfg(768, 1024, 768, 8, 8, 8, 6, 5), B=256, L=16, name="C3 geometry at 4x the batch (B256xL16; not a BASELINE config: shows what the fixed cost per launch hides at B64)"),
     "c3l24": dict(cfg=model_cfg(768, 1024, 768, 8, 8, 8, 6, 5), B=64, L=24, name="C3 roberta-large 1024 + wav2vec2 768, B64xL24 (SURVEY 8-d secondary length)"),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md

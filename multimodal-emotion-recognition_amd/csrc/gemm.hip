@@ -24,6 +24,7 @@
 //     wgrad form also emits the bias gradient (column sums of dY) from the tiles it already streams.
 #include "common.h"
 #include "ops.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <cstring>
@@ -1265,6 +1266,14 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
         if (ring && auto_tile && count_tiles(256, 128) >= ring256_min && m2f_gemm_ring256_ok(gb)) return m2f_launch_gemm_ring(gb, 256, 128, stream);
         // (what the 256x128 ring form cannot take - it has bias / ReLU / GELU / residual epilogues only - keeps the register-staged
         // 256x128 build from 1,024 such tiles on: RoBERTa-large geometry 52.3 vs 54.0 ms with 128x128 ring tiles)
+        // launches of 257..511 tiles of 128x128 take two rounds on 256 CUs with the second one mostly empty (the merged audio +
+        // text QKV in-projections at C3: 336 tiles); as 256x128 tiles they are one round (168 tiles).  M2F_RING256_2R=0 switches it off
+        static const int ring256_2r = getenv("M2F_RING256_2R") ? atoi(getenv("M2F_RING256_2R")) : 1;
+        if (ring && auto_tile && ring256_2r && tile != 256) {
+            const int t128 = count_tiles(128, 128);
+            if (t128 > 256 && t128 < 512 && count_tiles(256, 128) <= 256 && m2f_gemm_ring256_ok(gb) && m2f_gemm_ring_ok(gb))
+                return m2f_launch_gemm_ring(gb, 256, 128, stream);
+        }
         if (ring && auto_tile && tile != 256 && m2f_gemm_ring_ok(gb)) {
             if (count_tiles(128, 128) >= ring_min) return m2f_launch_gemm_ring(gb, 128, 128, stream);
             if (count_tiles(128, 64) >= ring64_min) return m2f_launch_gemm_ring(gb, 128, 64, stream);
@@ -1378,6 +1387,83 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
         t += n;
     }
     return t;
+}
+
+int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin) {
+    constexpr int TILE = 128;
+    tile_rec.clear();
+    wg_begin.assign((size_t)n_wg + 1, 0);
+    if (n_wg < 1 || prs.size() > 65535) return -1;
+    auto rec = [](size_t p, int mt, int nt) { return (uint32_t)p | ((uint32_t)mt << 16) | ((uint32_t)nt << 24); };
+    std::vector<std::vector<uint32_t>> per_wg((size_t)n_wg);
+    if (walk == 0) {
+        // the order of m2f_gemm_table_layout (m fastest inside a problem), dealt as ring_xcd_remap deals it
+        std::vector<uint32_t> all;
+        for (size_t p = 0; p < prs.size(); ++p) {
+            const int tm = m2f_cdiv(prs[p].M, TILE), tn = m2f_cdiv(prs[p].N, TILE);
+            if (tm > 255 || tn > 255) return -1;
+            for (int nt = 0; nt < tn; ++nt)
+                for (int mt = 0; mt < tm; ++mt) all.push_back(rec(p, mt, nt));
+        }
+        const int q = n_wg >> 3, r = n_wg & 7;
+        for (int b = 0; b < n_wg; ++b) {
+            const int x = b & 7, j = b >> 3;
+            const int first = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+            for (size_t t = (size_t)first; t < all.size(); t += (size_t)n_wg) per_wg[(size_t)b].push_back(all[t]);
+        }
+    } else {
+        // items = super-tiles of up to 8 (m) x 4 (n) tiles, problem-major, n-strip-major inside a problem (consecutive items
+        // of a strip share their column panels); the item list is cut into eight contiguous ranges of about equal tile count
+        struct Item { std::vector<uint32_t> tiles; };
+        std::vector<Item> items;
+        size_t total = 0;
+        for (size_t p = 0; p < prs.size(); ++p) {
+            const int tm = m2f_cdiv(prs[p].M, TILE), tn = m2f_cdiv(prs[p].N, TILE);
+            if (tm > 255 || tn > 255) return -1;
+            const int sm = tm < 8 ? tm : 8;
+            int sn = 32 / sm; if (sn < 1) sn = 1; if (sn > tn) sn = tn;
+            for (int n0 = 0; n0 < tn; n0 += sn)
+                for (int m0 = 0; m0 < tm; m0 += sm) {
+                    Item it;
+                    for (int nt = n0; nt < std::min(tn, n0 + sn); ++nt)
+                        for (int mt = m0; mt < std::min(tm, m0 + sm); ++mt) it.tiles.push_back(rec(p, mt, nt));
+                    total += it.tiles.size();
+                    items.push_back(std::move(it));
+                }
+        }
+        const int n_x = n_wg < 8 ? 1 : 8;
+        std::vector<std::vector<uint32_t>> seq((size_t)n_x);
+        size_t done = 0, i = 0;
+        for (int x = 0; x < n_x; ++x) {
+            const size_t target = total * (size_t)(x + 1) / (size_t)n_x;        // cumulative share after XCD x
+            while (i < items.size() && (x == n_x - 1 || done + items[i].tiles.size() / 2 < target)) {
+                seq[(size_t)x].insert(seq[(size_t)x].end(), items[i].tiles.begin(), items[i].tiles.end());
+                done += items[i].tiles.size();
+                ++i;
+            }
+        }
+        // workgroups of XCD x: b = x, x + 8, ... ; the j-th of them takes elements j, j + per_x, ... of the XCD's sequence
+        for (int x = 0; x < n_x; ++x) {
+            std::vector<int> wgs;
+            for (int b = x; b < n_wg; b += n_x) wgs.push_back(b);
+            for (size_t t = 0; t < seq[(size_t)x].size(); ++t) per_wg[(size_t)wgs[t % wgs.size()]].push_back(seq[(size_t)x][t]);
+        }
+    }
+    for (int b = 0; b < n_wg; ++b) {
+        wg_begin[(size_t)b] = (int)tile_rec.size();
+        tile_rec.insert(tile_rec.end(), per_wg[(size_t)b].begin(), per_wg[(size_t)b].end());
+    }
+    wg_begin[(size_t)n_wg] = (int)tile_rec.size();
+    {   // every tile of every problem exactly once, whatever the order
+        std::vector<uint32_t> got = tile_rec, want;
+        for (size_t p = 0; p < prs.size(); ++p)
+            for (int nt = 0; nt < m2f_cdiv(prs[p].N, TILE); ++nt)
+                for (int mt = 0; mt < m2f_cdiv(prs[p].M, TILE); ++mt) want.push_back(rec(p, mt, nt));
+        std::sort(got.begin(), got.end());
+        std::sort(want.begin(), want.end());
+        if (got != want) return -1;
+    }
+    return (int)tile_rec.size();
 }
 
 #ifdef M2F_EXP_TIMING

@@ -17,8 +17,18 @@ namespace {
 #ifdef M2F_EXP_TIMING
 __device__ unsigned long long m2f_ring_dbg[64];
 #define M2F_TS(slot) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) m2f_ring_dbg[(slot) + (threadIdx.x >= 256 ? 16 : 0)] = __builtin_amdgcn_s_memtime(); } while (0)
+// accumulating form (table kernel, one workgroup walks many tiles): slot += cycles; the host zeroes the buffer before the launch
+#define M2F_NOW() __builtin_amdgcn_s_memtime()
+// (sums are kept in registers and written once when the role ends: a memory update per k-tile would be what gets measured)
+#define M2F_ACC_DECL unsigned long long m2f_acc_[4] = {0ull, 0ull, 0ull, 0ull}
+#define M2F_ADD(slot, dt) do { m2f_acc_[(slot) - 8] += (unsigned long long)(dt); } while (0)
+#define M2F_ACC_FLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) { for (int q_ = 0; q_ < 4; ++q_) m2f_ring_dbg[8 + q_ + (threadIdx.x >= 256 ? 16 : 0)] += m2f_acc_[q_]; } } while (0)
 #else
 #define M2F_TS(slot) do {} while (0)
+#define M2F_NOW() 0ull
+#define M2F_ACC_DECL do {} while (0)
+#define M2F_ADD(slot, dt) do { (void)sizeof(dt); } while (0)
+#define M2F_ACC_FLUSH() do {} while (0)
 #endif
 
 typedef unsigned int ring_u32x4 __attribute__((ext_vector_type(4)));
@@ -274,27 +284,30 @@ __device__ __forceinline__ int ring_problem_of(const GemmBatch& gb, int bpos) {
 // table; the index is made provably uniform so that these are scalar loads.
 struct RingDesc {
     const uint16_t* aq[2]; const uint16_t* bq[2];
-    int M, N, k[2], ldaq[2], ldbq[2], tile_begin, pi;
+    int M, N, k[2], ldaq[2], ldbq[2], pi, m0, n0;
     uint32_t flags;
     float* bias_grad;           // TABLE + RC form only (the weight-gradient launch sums the bias gradients itself)
 };
-template <bool TABLE>
+template <bool TABLE, int BM, int BN>
 __device__ __forceinline__ RingDesc ring_desc(const GemmBatch& gb, int bpos) {
     RingDesc D;
     if constexpr (TABLE) {
-        D.pi = __builtin_amdgcn_readfirstlane((int)gb.tile_prob[bpos]);
+        const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)gb.tile_rec[bpos]);
+        D.pi = (int)(rec & 0xFFFFu); D.m0 = (int)((rec >> 16) & 0xFFu) * BM; D.n0 = (int)(rec >> 24) * BN;
         const GemmProblem& P = gb.table[D.pi];
         D.aq[0] = P.a.q[0]; D.aq[1] = P.a.q[0]; D.bq[0] = P.b.q[0]; D.bq[1] = P.b.q[0];
         D.M = P.M; D.N = P.N; D.k[0] = P.a.k[0]; D.k[1] = 0;
         D.ldaq[0] = P.a.ldq[0]; D.ldaq[1] = P.a.ldq[0]; D.ldbq[0] = P.b.ldq[0]; D.ldbq[1] = P.b.ldq[0];
-        D.tile_begin = P.tile_begin; D.flags = P.flags; D.bias_grad = P.bias_grad;      // (k-contiguous tables carry neither)
+        D.flags = P.flags; D.bias_grad = P.bias_grad;      // (k-contiguous tables carry neither)
     } else {
         D.pi = ring_problem_of(gb, bpos);
         const GemmHot& H = gb.hot[D.pi];
         D.aq[0] = H.aq[0]; D.aq[1] = H.aq[1]; D.bq[0] = H.bq[0]; D.bq[1] = H.bq[1];
         D.M = H.M; D.N = H.N; D.k[0] = H.k[0]; D.k[1] = H.k[1];
         D.ldaq[0] = H.ldaq[0]; D.ldaq[1] = H.ldaq[1]; D.ldbq[0] = H.ldbq[0]; D.ldbq[1] = H.ldbq[1];
-        D.tile_begin = H.tile_begin; D.flags = H.flags; D.bias_grad = nullptr;
+        D.flags = H.flags; D.bias_grad = nullptr;
+        const int tl = bpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
+        D.m0 = (tl % tiles_m) * BM; D.n0 = (tl / tiles_m) * BN;
     }
     return D;
 }
@@ -359,9 +372,8 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
         }
     };
     auto load_desc = [&]() {
-        const RingDesc H = ring_desc<TABLE>(gb, ibpos);
-        const int tl = ibpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
-        im0 = (tl % tiles_m) * BM; in0 = (tl / tiles_m) * BN;
+        const RingDesc H = ring_desc<TABLE, BM, BN>(gb, ibpos);
+        im0 = H.m0; in0 = H.n0;
         ink0 = (H.k[0] + BK - 1) / BK; ink = ink0 + (H.k[1] + BK - 1) / BK;
         kp0 = (H.k[0] + 7) & ~7; kp1 = (H.k[1] + 7) & ~7;
         ald0 = H.ldaq[0]; ald1 = H.ldaq[1]; bld0 = H.ldbq[0]; bld1 = H.ldbq[1];
@@ -446,19 +458,25 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     ring_lds_barrier();                                              // (#0) k-tile 0 is in the ring
     M2F_TS(4);
     int g = 0;
+    M2F_ACC_DECL;
 #pragma unroll 1
     for (int bpos = first; bpos < total_tiles; bpos += grid) {
-        const RingDesc H = ring_desc<TABLE>(gb, bpos);
+        const RingDesc H = ring_desc<TABLE, BM, BN>(gb, bpos);
         const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt, ++g) {
             // the consumers multiply k-tile g; the slot of k-tile g - 1 was released at the last barrier
+            const unsigned long long tp0 = M2F_NOW();
             if (!idone) issue_next();
+            const unsigned long long tp1 = M2F_NOW();
             if (issued > g + 1) wait_landed(g + 1);
+            const unsigned long long tp2 = M2F_NOW();
             ring_lds_barrier();                                      // (#g+1)
+            M2F_ADD(8, tp1 - tp0); M2F_ADD(9, tp2 - tp1); M2F_ADD(10, M2F_NOW() - tp2); M2F_ADD(11, 1);
         }
     }
     M2F_TS(5);
+    M2F_ACC_FLUSH();
 }
 
 template <int BM, int BN, int S, bool TABLE, bool RC, int EPI>
@@ -486,12 +504,13 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
     }
     int slot = 0;
     M2F_TS(0);
+    M2F_ACC_DECL;
 #pragma unroll 1
     for (int bpos = first; bpos < total_tiles; bpos += grid) {
-        const RingDesc H = ring_desc<TABLE>(gb, bpos);
+        const unsigned long long tc0 = M2F_NOW();
+        const RingDesc H = ring_desc<TABLE, BM, BN>(gb, bpos);
         const GemmProblem& P = TABLE ? gb.table[H.pi] : gb.pr[H.pi];
-        const int tl = bpos - H.tile_begin, tiles_m = (H.M + BM - 1) / BM;
-        const int m0 = (tl % tiles_m) * BM, n0 = (tl / tiles_m) * BN;
+        const int m0 = H.m0, n0 = H.n0;
         const int nk = (H.k[0] + BK - 1) / BK + (H.k[1] + BK - 1) / BK;
         const bool reluA = H.flags & GF_RELU_A, reluB = RC && (H.flags & GF_RELU_B);
         const bool bgrad = RC && H.bias_grad && n0 == 0 && wn == 0;      // wave-uniform: this wave sums its rows of A over k
@@ -585,6 +604,7 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
         };
         const RingEpi E = ring_epilogue_args<BM, BN>(gb, P, m0, n0);
         M2F_TS(1);
+        const unsigned long long tc1 = M2F_NOW();
         {
             const std::true_type T1{}; const std::false_type F0{};
             if constexpr (RC) {
@@ -611,18 +631,24 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
             }
         }
         M2F_TS(3);
+        const unsigned long long tc2 = M2F_NOW();
         ring_epilogue<MI, NI, BM, BN, EPI>(gb, E, acc, m0, n0, lane, wm, wn, smem + C::LDS + wave * 4096);
         M2F_TS(4);
+        M2F_ADD(8, tc1 - tc0); M2F_ADD(9, tc2 - tc1); M2F_ADD(10, M2F_NOW() - tc2); M2F_ADD(11, 1);
     }
     ring_lds_barrier();                                                  // matches the producers' last barrier
+    M2F_ACC_FLUSH();
 }
 
 template <int BM, int BN, int S, bool TABLE, bool RC = false, int EPI = (TABLE ? 1 : 0)>
 __global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
-    const int total_tiles = gb.total_tiles, grid = (int)gridDim.x;
-    const int first = ring_xcd_remap((int)blockIdx.x, grid);
+    // grouped launches: workgroup b walks tiles remap(b), + grid, ... of the launch's tile list; TABLE form: its own list
+    // (gb.tile_rec[gb.wg_begin[b] .. gb.wg_begin[b + 1]), built by m2f_gemm_table_walk)
+    const int grid = TABLE ? 1 : (int)gridDim.x;
+    const int total_tiles = TABLE ? __builtin_amdgcn_readfirstlane(gb.wg_begin[blockIdx.x + 1]) : gb.total_tiles;
+    const int first = TABLE ? __builtin_amdgcn_readfirstlane(gb.wg_begin[blockIdx.x]) : ring_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (threadIdx.x >= 256) ring_producer<BM, BN, S, TABLE, RC>(gb, smem, wave, lane, first, grid, total_tiles);      // wave-uniform
     else ring_consumer<BM, BN, S, TABLE, RC, EPI>(gb, smem, wave, lane, first, grid, total_tiles);
 }
@@ -644,6 +670,11 @@ hipError_t launch_ring_grid(const GemmBatch& hb, int t, hipStream_t stream) {
         attr_set = true;
     }
     ++m2f_g_ring_launches;
+    if constexpr (TABLE) {
+        if (!hb.tile_rec || !hb.wg_begin || hb.wg_count < 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(kern, dim3(hb.wg_count), dim3(512), C::LDS_ALL, stream, hb);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(t < n_cu ? t : n_cu), dim3(512), C::LDS_ALL, stream, hb);
     return hipGetLastError();
 }

@@ -8,3 +8,14 @@ hipError_t m2f_ring_launch_table_128x128(const GemmBatch& gb, hipStream_t stream
 hipError_t m2f_ring_launch_table_rc_128x128(const GemmBatch& gb, hipStream_t stream) {
     return launch_ring_grid<128, 128, 4, true, true>(gb, gb.total_tiles, stream);
 }
+#ifdef M2F_EXP_TIMING
+// diagnostic build only (make ttiming): phase totals of workgroup 0 of the table launches, see tools/table_timing.py
+extern "C" int m2f_ring_table_dbg_read(unsigned long long* out, int reset) {
+    int r = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(m2f_ring_dbg), sizeof(unsigned long long) * 64);
+    if (reset) {
+        unsigned long long z[64] = {0};
+        r |= (int)hipMemcpyToSymbol(HIP_SYMBOL(m2f_ring_dbg), z, sizeof(z));
+    }
+    return r;
+}
+#endif

@@ -1196,14 +1196,31 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together, so bytes per FLOP decide).
     if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : table_tile, tile_prob, table_rc);
     if (total_tiles <= 0) table_ok = false;
+    // ring table forms: per-workgroup tile lists (m2f_gemm_table_walk).  M2F_TABLE_WALK=0 (read when a plan is built) keeps the
+    // order of the tile list; default 1 = every XCD walks its own problems in 8 x 4 super-tiles
+    std::vector<uint32_t> tile_rec;
+    std::vector<int> wg_begin;
+    const bool table_ring = table_tile == 129 || table_tile == 130;
+    int wg_count = 0;
+    if (table_ok && table_ring) {
+        const char* walk_env = getenv("M2F_TABLE_WALK");
+        wg_count = std::min(total_tiles, 256);
+        if (m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, wg_count, tile_rec, wg_begin) != total_tiles) table_ok = false;
+    }
     GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;
     uint16_t* d_tile_prob = table_ok ? bld.ar.alloc<uint16_t>(tile_prob.size()) : nullptr;
+    uint32_t* d_tile_rec = table_ok && table_ring ? bld.ar.alloc<uint32_t>(tile_rec.size()) : nullptr;
+    int* d_wg_begin = table_ok && table_ring ? bld.ar.alloc<int>(wg_begin.size()) : nullptr;
     TransItem* d_items = table_ok ? bld.ar.alloc<TransItem>(titems.size()) : nullptr;
     uint16_t* d_tblock = table_ok ? bld.ar.alloc<uint16_t>(tblock.size()) : nullptr;
     P.ws_used = bld.ar.off;
     if (table_ok && P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
         bool ok = hipMemcpy(d_table, tprobs.data(), tprobs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(d_tile_prob, tile_prob.data(), tile_prob.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+        if (table_ring) {
+            ok = ok && hipMemcpy(d_tile_rec, tile_rec.data(), tile_rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+            ok = ok && hipMemcpy(d_wg_begin, wg_begin.data(), wg_begin.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+        }
         if (!titems.empty()) {
             ok = ok && hipMemcpy(d_items, titems.data(), titems.size() * sizeof(TransItem), hipMemcpyHostToDevice) == hipSuccess;
             ok = ok && hipMemcpy(d_tblock, tblock.data(), tblock.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
@@ -1213,6 +1230,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
             P.wg_trans = {d_items, d_tblock, (int)tblock.size(), T};
             memset(&P.wg_tab, 0, sizeof(P.wg_tab));
             P.wg_tab.table = d_table; P.wg_tab.tile_prob = d_tile_prob; P.wg_tab.total_tiles = total_tiles; P.wg_tab.table_tile = table_tile;
+            P.wg_tab.tile_rec = d_tile_rec; P.wg_tab.wg_begin = d_wg_begin; P.wg_tab.wg_count = wg_count;
             P.wg_tab.rng = P.rng; P.wg_tab.drop_thresh = P.drop_thresh; P.wg_tab.drop_scale = P.drop_scale;
         }
     }
@@ -1493,9 +1511,10 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
     return plan->bufs[which];
 }
 
-int m2f_plan_persistent(m2f_plan* plan) { return (plan->mfwd.on ? 1 : 0) | (plan->mbwd.on ? 2 : 0); }
+int m2f_plan_persistent(m2f_plan* plan) { return plan ? (plan->mfwd.on ? 1 : 0) | (plan->mbwd.on ? 2 : 0) : 0; }
 
 int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
+    if (!plan || !out8) return fail("m2f_plan_status: NULL plan (destroyed?) or output");
     for (int i = 0; i < 8; ++i) out8[i] = 0u;
     if (!plan->mega_status || !(plan->mfwd.on || plan->mbwd.on)) return 0;
     M2F_HIP(hipMemcpy(out8, plan->mega_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1510,6 +1529,7 @@ int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
 
 /* diagnostic (-DM2F_MEGA_PROF builds): the persistent kernels' tick table, [2 runs][8 kinds][8 fields]; clears it */
 int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
+    if (!plan) return fail("m2f_plan_prof: NULL plan (destroyed?)");
     if (!plan->mfwd.on || !plan->mfwd.args.prof) return fail("no persistent kernels in this plan");
     M2F_HIP(hipMemcpy(out128, plan->mfwd.args.prof, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     M2F_HIP(hipMemset(plan->mfwd.args.prof, 0, 128 * sizeof(unsigned long long)));
@@ -1517,6 +1537,7 @@ int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
 }
 
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
+    if (!plan) return -1;
     if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + plan->casts.size());
     if (phase == 1) return 2;
     return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() + plan->wg_casts.size() : plan->wg.size()) + plan->lnred.size());
@@ -1532,13 +1553,20 @@ static int do_forward(m2f_plan& P, hipStream_t s) {
     return run_launches(P, P.fwd, s);
 }
 
-int m2f_forward(m2f_plan* plan, m2f_stream_t stream) { return do_forward(*plan, static_cast<hipStream_t>(stream)); }
+int m2f_forward(m2f_plan* plan, m2f_stream_t stream) {
+    if (!plan) return fail("m2f_forward: NULL plan (destroyed?)");
+    return do_forward(*plan, static_cast<hipStream_t>(stream));
+}
 
 int m2f_loss(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream) {
+    if (!plan) return fail("m2f_loss: NULL plan (destroyed?)");
     return do_loss(*plan, label_smoothing, use_class_weights, normalise, static_cast<hipStream_t>(stream));
 }
 
-int m2f_backward(m2f_plan* plan, m2f_stream_t stream) { return do_backward(*plan, static_cast<hipStream_t>(stream)); }
+int m2f_backward(m2f_plan* plan, m2f_stream_t stream) {
+    if (!plan) return fail("m2f_backward: NULL plan (destroyed?)");
+    return do_backward(*plan, static_cast<hipStream_t>(stream));
+}
 
 static int step_body(m2f_plan& P, float ls, int cw, int normalise, hipStream_t s) {
     if (P.use_dropout) M2F_HIP(m2f_launch_rng_advance(P.rng, s));
@@ -1549,6 +1577,7 @@ static int step_body(m2f_plan& P, float ls, int cw, int normalise, hipStream_t s
 
 int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, int use_graph,
              m2f_stream_t stream) {
+    if (!plan) return fail("m2f_step: NULL plan (destroyed?)");
     m2f_plan& P = *plan;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!P.train) return fail("m2f_step needs a train plan");
@@ -1575,6 +1604,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
 
 int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream,
                    int max_entries, int* kinds, float* ms, double* flops) {
+    if (!plan) { fail("m2f_step_timed: NULL plan (destroyed?)"); return -1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     Profiler prof;
     prof.s = s;

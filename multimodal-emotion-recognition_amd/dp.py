@@ -33,8 +33,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:                              # M2F_DIST_BACKEND=gloo: several ranks sharing ONE GPU (rehearsals / tests)
+            backend = os.environ.get("M2F_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         # RCCL prints a version banner on STDOUT when the communicator is created (lazily, at the first collective);
@@ -98,6 +98,27 @@ def broadcast_from_rank0(values: Sequence[float], device=None) -> List[float]:
     return t.cpu().tolist()
 
 
+class _StagedWork:
+    """gloo has no device collectives on this build: a CUDA tensor is summed through a host copy.  Same interface as the
+    Work object of an asynchronous collective (only `wait`), same stream semantics as RCCL's: after `wait()` the current
+    stream may read the result."""
+
+    def __init__(self, t: torch.Tensor, group):
+        self.t, self.group = t, group
+
+    def wait(self) -> None:
+        host = self.t.detach().to("cpu", torch.float32)        # (synchronises with the current stream: the producers are done)
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        self.t.copy_(host.to(self.t.dtype))
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None):
+    """Asynchronous SUM all-reduce of `t` -> an object with wait()."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return _StagedWork(t, group)
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 class GradReducer:
     """Sum-all-reduce of [flat gradients | den | num] in `n_buckets` contiguous chunks.
 
@@ -124,7 +145,7 @@ class GradReducer:
             # probe once, on every rank alike: a backend without bf16 reductions falls back to the exact fp32 exchange
             try:
                 probe = torch.zeros(64, dtype=torch.bfloat16, device=buf.device)
-                dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=group)
+                _all_reduce_sum(probe, group).wait()
             except (RuntimeError, ValueError, TypeError) as e:          # pragma: no cover - depends on the backend build
                 import sys
                 print(f"mer_amd.dp: bf16 all-reduce unavailable ({e}); using the fp32 gradient exchange", file=sys.stderr)
@@ -151,8 +172,7 @@ class GradReducer:
     def all_reduce(self, async_op: bool = False) -> None:
         if not dist.is_initialized():
             return                                   # single process: nothing to exchange
-        self._work = [dist.all_reduce(self.buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                      for a, b in self.chunks]
+        self._work = [_all_reduce_sum(self.buf[a:b], self.group) for a, b in self.chunks]
         if not async_op:
             self.wait()
 
@@ -170,12 +190,12 @@ class GradReducer:
             return
         if self.exchange == "bf16":
             tail = self.buf[self.n:]
-            work_tail = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # (loss, den, num): fp32
+            work_tail = _all_reduce_sum(tail, self.group)   # (loss, den, num): fp32
             order = list(reversed(self.param_chunks))
             work = []
             for a, b in order:
                 self.buf16[a:b].copy_(self.buf[a:b])                     # one rounding per rank, on the device
-                work.append(dist.all_reduce(self.buf16[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                work.append(_all_reduce_sum(self.buf16[a:b], self.group))
 
             def wait(i):
                 if i == 0:
@@ -184,7 +204,7 @@ class GradReducer:
             optimizer.step_ranges(order, before_each=wait, grads=self.buf16)
             return
         order = list(reversed(self.chunks))
-        work = [dist.all_reduce(self.buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a, b in order]
+        work = [_all_reduce_sum(self.buf[a:b], self.group) for a, b in order]
         optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
 
     @property
@@ -193,6 +213,26 @@ class GradReducer:
 
     def global_loss(self) -> torch.Tensor:
         return self.buf[self.n + 2] / self.buf[self.n + 1]
+
+
+def sum_over_ranks(values: Sequence[float], device=None) -> List[float]:
+    """SUM over ranks, float64 (per-batch validation sums: every rank ends with the same totals)."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if t.device.type == "cpu" and dist.get_backend() == "nccl":
+            t = t.cuda()
+        elif t.device.type == "cuda" and dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().tolist()
+
+
+def dropout_seed(initial_seed: int, rank: int) -> Tuple[int, int]:
+    """(lo, hi) 32-bit words of the dropout generator's seed on `rank`: the process seed with the rank folded in, so that the
+    replicas (same torch seed = same initial weights) draw DIFFERENT masks for their different dialogues - rank 0 keeps the
+    single-process stream."""
+    seed = (int(initial_seed) ^ (int(rank) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    return seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
 
 
 def reduce_metrics(values: Sequence[float], device=None) -> List[float]:

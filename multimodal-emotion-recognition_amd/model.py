@@ -119,11 +119,15 @@ class _Anchor(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         plan = ctx.plan
+        if not plan.handle:
+            raise RuntimeError("M2FNet: the plan holding the activations of this forward was destroyed")
         if plan.version != ctx.version:
             raise RuntimeError("M2FNet: the activations of this forward were overwritten by a later forward of the "
-                               "same (B, L) shape; call backward() before the next forward()")
+                               "same plan shape (more graphs were kept alive than the plan cache may hold - raise "
+                               "M2F_MAX_PLANS / M2F_MAX_PLAN_BYTES, or call backward() before further forwards)")
         plan.set_dlogits(dlogits)
         plan.backward()
+        plan.release()                                    # (a second backward through the same graph re-runs on the same buffers)
         ctx.model._engine.publish_grads()
         return None, None, None
 
@@ -152,13 +156,19 @@ class _Engine:
                 view.copy_(p.detach().to(device=device, dtype=torch.float32))
                 p.data = view
                 self.items.append((p, sp.offset, sp.numel, sp.shape))
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        from .dp import dropout_seed
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        lo, hi = dropout_seed(torch.initial_seed(), rank)     # replicas share weights (same seed) but not dropout masks
         to_i32 = lambda u: u - (1 << 32) if u >= (1 << 31) else u
         self.rng = torch.tensor([to_i32(lo), to_i32(hi), 0, 0], dtype=torch.int32, device=device)
-        # plan cache: least-recently-used first; at most `max_plans` plans (workspaces + captured graphs) stay alive
+        # plan cache: least-recently-used first; at most `max_plans` plans / `max_plan_bytes` of workspaces (+ captured graphs)
+        # stay alive.  Keys are (shape bucket, mode, instance): a shape whose plan still holds the activations of a forward
+        # that has not run its backward yet (`Plan.busy`) gets a second instance instead of overwriting them, so
+        # `forward(A); forward(B); loss_A.backward()` works as it does in the reference when A and B share a bucket.
+        # Shape buckets make the working set of a training run 3 L-buckets x {full, last partial batch} x {train, eval}.
         self.plans: "collections.OrderedDict[Tuple, runtime.Plan]" = collections.OrderedDict()
-        self.max_plans = int(os.environ.get("M2F_MAX_PLANS", "6"))
+        self.max_plans = int(os.environ.get("M2F_MAX_PLANS", "16"))
+        self.max_plan_bytes = int(float(os.environ.get("M2F_MAX_PLAN_BYTES", str(96 * 2 ** 30))))
         self.shape_buckets = model.shape_buckets
         self.grad_views = None
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -196,8 +206,20 @@ class _Engine:
             Tb = (need + 63) // 64 * 64
             if Tb <= 0.85 * B * L:
                 T = max(Tb, B)
-        key = (B, L, T, want_backward, dropout_active, self.precision)
-        pl = self.plans.get(key)
+        base = (B, L, T, want_backward, dropout_active, self.precision)
+        inst, key, pl, oldest = 0, None, None, None
+        while True:                                       # first instance of this shape that no live autograd graph owns
+            key = base + (inst,)
+            pl = self.plans.get(key)
+            if pl is None or not pl.busy():
+                break
+            oldest = oldest or key
+            inst += 1
+        if pl is None:
+            if inst > 0 and not self._room_for(self.plans[oldest].nbytes()):
+                # no room for another instance: hand out the least recently used one (its pending backward will raise)
+                key = next(k for k in self.plans if k[:-1] == base)
+                pl = self.plans[key]
         if pl is None:
             cfg = self.cfg
             if not dropout_active and cfg.dropout != 0.0:
@@ -206,19 +228,32 @@ class _Engine:
             train = want_backward or dropout_active
             if train:
                 self.ensure_grad()
-            self._evict(max(self.max_plans, 1) - 1)
+            self._evict(max(self.max_plans, 1) - 1, self.max_plan_bytes)
             pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng, T=T)
             self.plans[key] = pl
+            self._evict(max(self.max_plans, 1), self.max_plan_bytes, protect=key)
         else:
             self.plans.move_to_end(key)
-            self._evict(max(self.max_plans, 1))
+            self._evict(max(self.max_plans, 1), self.max_plan_bytes, protect=key)      # (the caps may have been lowered since)
         return pl
 
-    def _evict(self, keep: int) -> None:
-        """Drop least-recently-used plans until at most `keep` are left: frees their workspaces and captured graphs."""
-        while len(self.plans) > keep:
-            _, old = self.plans.popitem(last=False)
-            torch.cuda.synchronize(self.device)                        # nothing queued may still use them
+    def _room_for(self, nbytes: int) -> bool:
+        """Could one more plan of `nbytes` be cached after evicting every idle plan?"""
+        busy = [p for p in self.plans.values() if p.busy()]
+        return len(busy) + 1 <= max(self.max_plans, 1) and sum(p.nbytes() for p in busy) + nbytes <= self.max_plan_bytes
+
+    def _evict(self, keep: int, keep_bytes: Optional[int] = None, protect=None) -> None:
+        """Drop least-recently-used IDLE plans until at most `keep` plans / `keep_bytes` of workspaces are left: frees their
+        workspaces and captured graphs.  A plan whose activations a live autograd graph still needs is never closed."""
+        def over():
+            return len(self.plans) > keep or (keep_bytes is not None and self.plan_bytes() > keep_bytes and len(self.plans) > 1)
+        for k in list(self.plans):
+            if not over():
+                break
+            if k == protect or self.plans[k].busy():
+                continue
+            old = self.plans.pop(k)
+            torch.cuda.synchronize(self.device)                        # nothing queued may still use it
             old.close()
 
     def plan_bytes(self) -> int:
@@ -322,7 +357,9 @@ class M2FNet(nn.Module):
         plan = eng.plan(B, L, want_bwd, self.training and self.m2f_config.dropout > 0.0, valid)
         plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask)
         if want_bwd:
-            return _Anchor.apply(eng.anchor, self, plan)
+            out = _Anchor.apply(eng.anchor, self, plan)
+            plan.hold(out.grad_fn)
+            return out
         if plan.train and plan.cfg.dropout > 0.0:
             runtime.check(runtime.lib().m2f_rng_advance(eng.rng.data_ptr(), runtime.stream_ptr()), "m2f_rng_advance")
         return plan.forward().clone()

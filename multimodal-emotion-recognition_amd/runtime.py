@@ -231,6 +231,7 @@ class Plan:
         # result views below are cut to the batch
         self.in_B, self.in_L = B, L
         self.version = 0          # bumped by every forward; backward checks it still owns the activations
+        self._pending = None      # weak reference to the autograd node whose backward still needs this plan's activations
 
     def _unpack(self, rows: torch.Tensor) -> torch.Tensor:
         """[T, C] rows of a packed plan -> the padded [b, l, C] surface of the last batch (pad slots = 0)."""
@@ -254,6 +255,13 @@ class Plan:
             return None
         return self._unpack(self._fam0_out) if self.packed else self._fam0_out[: self.in_B, : self.in_L]
 
+    def _h(self) -> int:
+        """The C handle; raises (instead of handing NULL to the library) once the plan was closed."""
+        if not self.handle:
+            raise HipError("this plan was closed (evicted from the engine's plan cache or destroyed): its workspace and launch "
+                           "lists are gone")
+        return self.handle
+
     def _view(self, which: int, shape, dtype) -> torch.Tensor:
         p = lib().m2f_plan_buffer(self.handle, which)
         if not p:
@@ -267,15 +275,27 @@ class Plan:
 
     def persistent(self) -> int:
         """bit 0 / bit 1: the forward / backward chain runs as one persistent strip-dataflow launch (csrc/mega.h)."""
-        return lib().m2f_plan_persistent(self.handle)
+        return lib().m2f_plan_persistent(self._h())
 
     def check_status(self) -> None:
         """Raises if a persistent kernel gave up on a bounded wait (synchronises with the device)."""
         out = (c_uint32 * 8)()
-        check(lib().m2f_plan_status(self.handle, out), "m2f_plan_status")
+        check(lib().m2f_plan_status(self._h(), out), "m2f_plan_status")
 
     def num_launches(self) -> Dict[str, int]:
-        return {k: lib().m2f_plan_num_launches(self.handle, i) for i, k in enumerate(("forward", "loss", "backward"))}
+        return {k: lib().m2f_plan_num_launches(self._h(), i) for i, k in enumerate(("forward", "loss", "backward"))}
+
+    def hold(self, node) -> None:
+        """A forward ran under autograd: `node` (its grad_fn) will call backward() on these activations."""
+        import weakref
+        self._pending = weakref.ref(node) if node is not None else None
+
+    def release(self) -> None:
+        self._pending = None
+
+    def busy(self) -> bool:
+        """True while an autograd graph that has not run its backward yet (and is still alive) owns the activations."""
+        return self._pending is not None and self._pending() is not None
 
     def set_inputs(self, text: Optional[torch.Tensor], audio: Optional[torch.Tensor], key_pad: torch.Tensor,
                    labels: Optional[torch.Tensor] = None) -> None:
@@ -287,6 +307,7 @@ class Plan:
         extra DIALOGUE keeps one unmasked, unlabeled slot (a fully masked dialogue would produce NaN logits in the reference
         too): it flows through the forward, contributes exactly zero to the loss and to every gradient,
         and its logits are cut off by the `logits` view.  Valid logits do not depend on padding (SURVEY 8-a fact i)."""
+        self._h()
         b, l = key_pad.shape if key_pad.dim() == 2 else (self.B, self.L)
         if b > self.B or l > self.L:
             raise HipError(f"batch {b} x {l} does not fit the plan {self.B} x {self.L}")
@@ -360,24 +381,24 @@ class Plan:
 
     def forward(self) -> torch.Tensor:
         self.version += 1
-        check(lib().m2f_forward(self.handle, stream_ptr()), "m2f_forward")
+        check(lib().m2f_forward(self._h(), stream_ptr()), "m2f_forward")
         return self.logits
 
     def nbytes(self) -> int:
         return self.workspace.numel()
 
     def loss_fwd(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True):
-        check(lib().m2f_loss(self.handle, label_smoothing, int(use_class_weights), int(normalise), stream_ptr()),
+        check(lib().m2f_loss(self._h(), label_smoothing, int(use_class_weights), int(normalise), stream_ptr()),
               "m2f_loss")
         return self.loss
 
     def backward(self) -> None:
-        check(lib().m2f_backward(self.handle, stream_ptr()), "m2f_backward")
+        check(lib().m2f_backward(self._h(), stream_ptr()), "m2f_backward")
 
     def step(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True,
              use_graph: bool = True) -> torch.Tensor:
         self.version += 1
-        check(lib().m2f_step(self.handle, label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
+        check(lib().m2f_step(self._h(), label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
                              stream_ptr()), "m2f_step")
         return self.loss
 
@@ -386,7 +407,7 @@ class Plan:
         self.version += 1
         n_max = 4096
         kinds, ms, fl = (c_int * n_max)(), (c_float * n_max)(), (ctypes.c_double * n_max)()
-        n = lib().m2f_step_timed(self.handle, label_smoothing, int(use_class_weights), int(normalise), stream_ptr(),
+        n = lib().m2f_step_timed(self._h(), label_smoothing, int(use_class_weights), int(normalise), stream_ptr(),
                                  n_max, kinds, ms, fl)
         if n < 0:
             raise HipError("m2f_step_timed: " + lib().m2f_last_error().decode())

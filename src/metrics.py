@@ -23,6 +23,10 @@ class BatchScores:
         self._f1 += f1_score(target, predicted, average="weighted")
         self.n_batches += 1
 
+    def sums(self):
+        """(sum of per-batch accuracies, sum of per-batch weighted-F1s) - what ranks add up under data parallelism."""
+        return self._acc, self._f1
+
     def result(self):
         """(accuracy, weighted_f1), each the plain mean of the per-batch scores."""
         n = max(self.n_batches, 1)

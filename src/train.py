@@ -93,6 +93,11 @@ def main(config=None):
     # global batch are sharded over the ranks, gradients are summed over RCCL with the GLOBAL valid-utterance denominator
     # (mer_amd/dp.py).  The reference is single-process (src/train.py:20); a single rank behaves exactly like it.
     want_dp = _runtime(config, "data_parallel", "auto")
+    if want_dp not in (True, "auto") and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # W independent trainings on one device, all writing the same checkpoint, is never what a launcher was asked for
+        raise RuntimeError(f"runtime.data_parallel is {want_dp!r} but this process was launched as one of "
+                           f"{os.environ['WORLD_SIZE']} ranks (WORLD_SIZE): set runtime.data_parallel to True / 'auto' or "
+                           "launch a single process")
     rank, world, local = dp.init_distributed() if want_dp in (True, "auto") else (0, 1, 0)
     device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
     if rank == 0:
@@ -201,6 +206,8 @@ def training_loop(model, dl_train, dl_val, criterion, optimizer, lr_scheduler, s
             break
     if log_to_wandb:
         wandb.finish()
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.barrier()                      # rank 0 may still be moving checkpoint files
     return history
 
 
@@ -241,20 +248,25 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
 
 def validate(model, dl_val, criterion, device):
     """-> (mean batch loss, accuracy, weighted_f1); scores by the per-batch rule of ``metrics.BatchScores``.
-    With several ranks the replicas are identical: rank 0 evaluates the whole split (the mean-of-batches rule needs the
-    reference's batches, src/train.py:245-272) and every rank receives its three numbers."""
-    if _rank() != 0:
-        return tuple(dp.broadcast_from_rank0([0.0, 0.0, 0.0], device=device))
+    With several ranks the replicas are identical and the rule is a plain mean over the reference's batches
+    (src/train.py:245-272), so rank r evaluates batches r, r + W, ... WHOLE and the per-batch sums are added over the ranks:
+    the same three numbers as the single-process loop, on every rank (early stopping decides alike everywhere)."""
+    rank = _rank()
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     model.eval()
     scores, loss_total = BatchScores(), 0.0
     with torch.inference_mode():
-        for batch in tqdm(dl_val, total=len(dl_val), desc="Validation"):
+        for i, batch in enumerate(tqdm(dl_val, total=len(dl_val), desc="Validation", disable=rank != 0)):
+            if i % world != rank:
+                continue
             text, audio, emotion, padding_mask = move_batch(batch, device)
             logits = model(text, audio, padding_mask)
             loss_total += criterion(logits.permute(0, 2, 1), emotion).item()
             scores.update(logits, emotion)
-    accuracy, weighted_f1 = scores.result()
-    return tuple(dp.broadcast_from_rank0([loss_total / len(dl_val), accuracy, weighted_f1], device=device))
+    acc_sum, f1_sum = scores.sums()
+    loss_total, acc_sum, f1_sum, n = dp.sum_over_ranks([loss_total, acc_sum, f1_sum, float(scores.n_batches)], device=device)
+    n = max(n, 1.0)
+    return loss_total / n, acc_sum / n, f1_sum / n
 
 
 if __name__ == "__main__":

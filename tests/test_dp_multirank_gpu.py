@@ -1,0 +1,80 @@
+"""Two REAL rank processes on the device (tests/dp_worker.py, started by conftest.py before this process touches the GPU):
+RCCL with one GPU per rank when the box has two, otherwise both ranks on cuda:0 exchanging through gloo.  What the
+world_size-2 gloo tests on the CPU (test_dp_cpu.py) cannot cover: the HIP step under a real second rank - sharded global
+batch against the single-process step on the union batch, rank-dependent dropout masks, and the whole training loop of
+src/train.py (sharded loader with an EMPTY shard, validation split over the ranks, early stopping, checkpoints from rank 0)
+against the single-process loop."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "src"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import synth  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.dp2]
+
+
+def test_two_rank_step_equals_single_process_step_on_the_union_batch(dp2_results):
+    from mer_amd.model import M2FNet
+    from mer_amd.optim import FusedAdam
+    (r0, r1), _ = dp2_results
+    assert r0["world"] == r1["world"] == 2 and {r0["rank"], r1["rank"]} == {0, 1}
+    assert r0["backend"] == ("nccl" if r0["n_gpu"] >= 2 else "gloo")
+    # both replicas took the same three steps
+    assert r0["A_losses"] == r1["A_losses"] and torch.equal(r0["A_params"], r1["A_params"])
+    cfg, B, L, lengths, kind = synth.CASES["tiny_ragged"]
+    batch = [t.cuda() for t in synth.make_inputs(cfg, B, L, lengths, kind)]
+    torch.manual_seed(0)
+    m = M2FNet(cfg, precision="fp32").to("cuda").train()
+    sd = synth.make_state_dict(cfg)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    start = m.flat_parameters().detach().cpu().clone()
+    opt = FusedAdam(m, lr=1e-3, weight_decay=0.01)
+    losses = []
+    for _ in range(3):
+        losses.append(float(m.train_step(*batch, use_graph=False)))
+        opt.step()
+    torch.cuda.synchronize()
+    ref = m.flat_parameters().detach().cpu()
+    # global-denominator loss of the sharded batch == mean-over-valid loss of the union batch
+    assert max(abs(a - b) for a, b in zip(r0["A_losses"], losses)) < 1e-5, (r0["A_losses"], losses)
+    rel = float(((r0["A_params"] - ref).double().norm() / (ref - start).double().norm()))
+    assert rel < 1e-4, rel                                  # (fp32: summation order of the two shards only)
+
+
+def test_ranks_draw_different_dropout_masks(dp2_results):
+    from mer_amd import dp
+    (r0, r1), _ = dp2_results
+    assert r0["B_rng"][:2].tolist() != r1["B_rng"][:2].tolist()
+    assert r0["B_rng"][2:].tolist() == r1["B_rng"][2:].tolist()          # same step counter
+    lo, hi = dp.dropout_seed(0, 1)
+    assert [x & 0xFFFFFFFF for x in r1["B_rng"][:2].tolist()] == [lo, hi]
+    g0, g1 = r0["B_grads"], r1["B_grads"]
+    assert torch.isfinite(g0).all() and torch.isfinite(g1).all()
+    # same weights, same batch, different masks: the gradients differ by much more than rounding
+    assert float((g0 - g1).norm() / g0.norm()) > 0.05
+
+
+def test_training_loop_under_two_ranks_equals_the_single_process_loop(dp2_results, tmp_path):
+    import dp_worker as W
+    (r0, r1), out_dir = dp2_results
+    h0, h1 = r0["C"]["history"], r1["C"]["history"]
+    assert h0 == h1 and len(h0["loss_values"]) >= 2                      # same losses, same (early) stop on both ranks
+    assert torch.equal(r0["C"]["params"], r1["C"]["params"])              # replicas stayed identical
+    assert len(h0["loss_values"]) < 6, "early stopping (patience 1) should have ended the run"
+    assert r0["C_files"] == ["m2fnet.pth"], r0["C_files"]                # best_weights.pth restored + removed, by rank 0 only
+    cfg = W.loop_config(str(tmp_path))
+    ref = W.run_training_loop(cfg, torch.device("cuda:0"), 1, 0)
+    assert len(ref["history"]["loss_values"]) == len(h0["loss_values"])
+    for a, b in zip(ref["history"]["loss_values"] + ref["history"]["val_loss_values"], h0["loss_values"] + h0["val_loss_values"]):
+        assert abs(a - b) < 5e-4 * max(1.0, abs(a)), (ref["history"], h0)
+    rel = float((r0["C"]["params"] - ref["params"]).double().norm() / ref["params"].double().norm())
+    assert rel < 1e-3, rel
+    ck_dp = torch.load(os.path.join(out_dir, "loop_dp", "ck", "m2fnet.pth"), weights_only=False)
+    ck_1 = torch.load(cfg.checkpoint.save_path, weights_only=False)
+    assert ck_dp["epoch"] == ck_1["epoch"] and list(ck_dp["model_state_dict"]) == list(ck_1["model_state_dict"])

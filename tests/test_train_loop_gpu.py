@@ -160,3 +160,79 @@ def test_plan_cache_is_bounded_over_real_dialogue_lengths():
         m.train_step(*batch, use_graph=True)
         assert len(eng.plans) <= 2
     torch.cuda.synchronize()
+
+
+def _grads_of(m):
+    return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+
+def test_two_forwards_in_one_bucket_then_backward_of_the_first():
+    """Reference order the plan cache must allow: `out_a = model(A); out_b = model(B); loss_a.backward()` with A and
+    B of different exact shapes in ONE shape bucket (L = 5 and L = 9 -> 16).  The second forward gets a plan instance of its
+    own instead of overwriting the activations the first graph still needs; both backward passes give the gradients of a
+    run that saw only that batch."""
+    from mer_amd.model import M2FNet
+    cfg = synth._cfg(40, 48, 64, 4, 4, 4, 1, 1, 1, dropout=0.0)
+    sd = synth.make_state_dict(cfg)
+
+    def fresh():
+        m = M2FNet(cfg)
+        m.load_state_dict(sd)
+        return m.to("cuda:0").train()
+
+    a = [t.cuda() for t in synth.make_inputs(cfg, 4, 5, [5, 2, 3, 1], "randn", seed=1)]
+    b = [t.cuda() for t in synth.make_inputs(cfg, 4, 9, [9, 4, 1, 7], "randn", seed=2)]
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)
+
+    def loss_of(m, batch):
+        return crit(m(batch[0], batch[1], batch[2]).permute(0, 2, 1), batch[3])
+
+    ref = {}
+    for name, batch in (("a", a), ("b", b)):
+        m = fresh()
+        loss_of(m, batch).backward()
+        ref[name] = _grads_of(m)
+    m = fresh()
+    la = loss_of(m, a)
+    lb = loss_of(m, b)
+    eng = m.engine()
+    assert len(eng.plans) == 2 and len({k[:-1] for k in eng.plans}) == 1          # one bucket, two instances
+    la.backward()
+    assert torch.equal(_grads_of(m), ref["a"])
+    lb.backward()
+    assert torch.equal(_grads_of(m), ref["b"])
+    # both graphs are done: the next forward of the bucket re-uses instance 0, no third plan appears
+    del la, lb
+    loss_of(m, a).backward()
+    assert len(eng.plans) == 2 and torch.equal(_grads_of(m), ref["a"])
+
+
+def test_busy_plan_survives_eviction_and_closed_plan_raises():
+    """`_evict` must not close a plan whose activations a live autograd graph still needs (it used to: the later backward
+    dereferenced a destroyed plan); a closed plan raises instead of handing NULL to the library."""
+    from mer_amd import runtime
+    from mer_amd.model import M2FNet
+    cfg = synth._cfg(40, 48, 64, 4, 4, 4, 1, 1, 1, dropout=0.0)
+    m = M2FNet(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg))
+    m = m.to("cuda:0").train()
+    eng = m.engine()
+    eng.max_plans = 1
+    a = [t.cuda() for t in synth.make_inputs(cfg, 4, 5, None, "randn", seed=1)]
+    c = [t.cuda() for t in synth.make_inputs(cfg, 4, 20, None, "randn", seed=3)]
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    la = crit(m(a[0], a[1], a[2]).permute(0, 2, 1), a[3])
+    pa = next(iter(eng.plans.values()))
+    with torch.no_grad():
+        m(c[0], c[1], c[2])                                  # another bucket: over the cap, but plan A is busy
+    assert pa.handle and pa.busy()
+    la.backward()                                            # ... so this still works
+    assert not pa.busy()
+    g = _grads_of(m)
+    assert torch.isfinite(g).all() and g.abs().max() > 0
+    with torch.no_grad():
+        m(c[0], c[1], c[2])                                  # now A is idle and goes
+    assert not pa.handle
+    with pytest.raises(runtime.HipError, match="closed"):
+        pa.forward()
+    torch.cuda.synchronize()

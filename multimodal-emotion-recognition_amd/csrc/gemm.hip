@@ -1389,8 +1389,8 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
     return t;
 }
 
-int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin) {
-    constexpr int TILE = 128;
+int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin) {
+    constexpr int TILE = 128;                                   // tile_n
     tile_rec.clear();
     wg_begin.assign((size_t)n_wg + 1, 0);
     if (n_wg < 1 || prs.size() > 65535) return -1;
@@ -1400,7 +1400,7 @@ int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg,
         // the order of m2f_gemm_table_layout (m fastest inside a problem), dealt as ring_xcd_remap deals it
         std::vector<uint32_t> all;
         for (size_t p = 0; p < prs.size(); ++p) {
-            const int tm = m2f_cdiv(prs[p].M, TILE), tn = m2f_cdiv(prs[p].N, TILE);
+            const int tm = m2f_cdiv(prs[p].M, tile_m), tn = m2f_cdiv(prs[p].N, TILE);
             if (tm > 255 || tn > 255) return -1;
             for (int nt = 0; nt < tn; ++nt)
                 for (int mt = 0; mt < tm; ++mt) all.push_back(rec(p, mt, nt));
@@ -1418,7 +1418,7 @@ int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg,
         std::vector<Item> items;
         size_t total = 0;
         for (size_t p = 0; p < prs.size(); ++p) {
-            const int tm = m2f_cdiv(prs[p].M, TILE), tn = m2f_cdiv(prs[p].N, TILE);
+            const int tm = m2f_cdiv(prs[p].M, tile_m), tn = m2f_cdiv(prs[p].N, TILE);
             if (tm > 255 || tn > 255) return -1;
             const int sm = tm < 8 ? tm : 8;
             int sn = 32 / sm; if (sn < 1) sn = 1; if (sn > tn) sn = tn;
@@ -1458,7 +1458,7 @@ int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg,
         std::vector<uint32_t> got = tile_rec, want;
         for (size_t p = 0; p < prs.size(); ++p)
             for (int nt = 0; nt < m2f_cdiv(prs[p].N, TILE); ++nt)
-                for (int mt = 0; mt < m2f_cdiv(prs[p].M, TILE); ++mt) want.push_back(rec(p, mt, nt));
+                for (int mt = 0; mt < m2f_cdiv(prs[p].M, tile_m); ++mt) want.push_back(rec(p, mt, nt));
         std::sort(got.begin(), got.end());
         std::sort(want.begin(), want.end());
         if (got != want) return -1;
@@ -1474,7 +1474,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile == 129 || gb.table_tile == 130) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
+    if (gb.table_tile == 129 || gb.table_tile == 130 || gb.table_tile == 131) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

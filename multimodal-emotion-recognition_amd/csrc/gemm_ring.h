@@ -22,7 +22,8 @@ __device__ unsigned long long m2f_ring_dbg[64];
 // (sums are kept in registers and written once when the role ends: a memory update per k-tile would be what gets measured)
 #define M2F_ACC_DECL unsigned long long m2f_acc_[4] = {0ull, 0ull, 0ull, 0ull}
 #define M2F_ADD(slot, dt) do { m2f_acc_[(slot) - 8] += (unsigned long long)(dt); } while (0)
-#define M2F_ACC_FLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) { for (int q_ = 0; q_ < 4; ++q_) m2f_ring_dbg[8 + q_ + (threadIdx.x >= 256 ? 16 : 0)] += m2f_acc_[q_]; } } while (0)
+// (wave 1 of the role: as a consumer it owns column block 1 and never carries the bias-gradient sums)
+#define M2F_ACC_FLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 64) { for (int q_ = 0; q_ < 4; ++q_) m2f_ring_dbg[8 + q_ + (threadIdx.x >= 256 ? 16 : 0)] += m2f_acc_[q_]; } } while (0)
 #else
 #define M2F_TS(slot) do {} while (0)
 #define M2F_NOW() 0ull
@@ -37,8 +38,16 @@ typedef short ring_s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float ring_bf16lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float ring_bf16hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 __device__ __forceinline__ uint32_t ring_relu_bf16x2(uint32_t v) {
-    const uint32_t m = ((v >> 15) & 0x00010001u) * 0xFFFFu;      // 0xFFFF in every half whose sign bit is set
-    return v & ~m;
+    // bf16 pairs as int16 pairs: sign bit set <=> negative int16, so max(., 0) zeroes exactly the halves the bit mask of
+    // gemm.hip's relu_bf16x2 zeroes (same result bits) in ONE v_pk_max_i16 instead of four integer operations
+    typedef short ring_s16x2 __attribute__((ext_vector_type(2)));
+    const ring_s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ring_s16x2, v), z));
+}
+// sum of the two bf16 halves of v added to acc (v_dot2c_f32_bf16 against (1, 1)): the bias-gradient row sums
+__device__ __forceinline__ float ring_bf16x2_sum(uint32_t v, float acc) {
+    typedef __bf16 ring_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ring_bf16x2, v), __builtin_bit_cast(ring_bf16x2, 0x3F803F80u), acc, false);
 }
 // XCD-aware block order (gemm.hip, xcd_remap): every XCD walks a contiguous range of the launch's tile list
 __device__ __forceinline__ int ring_xcd_remap(int b, int nblocks) {
@@ -349,14 +358,32 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
             // image is k-major, 256-byte rows of 128 features; a 1 KiB piece = 4 k-rows, lane -> (k-row lane >> 4, chunk
             // position lane & 15), the 16-byte chunk stored at a position is pos ^ (4 * (k-row & 3)) - which spreads the four
             // k-rows of a transposing fragment read (ds_read_b64_tr_b16) over four disjoint bank ranges
-            static_assert(!RC || (BM == 128 && BN == 128), "RC form: 256-byte tile rows");
+            // (a 256-wide operand is two such images of 128 features behind each other: piece p belongs to image p / 16)
+            static_assert(!RC || ((BM == 128 || BM == 256) && BN == 128), "RC form: 256-byte tile rows");
             const int kr = lane >> 4, p16 = lane & 15;
+#if defined(M2F_RING_EXP_ADDR)      // timing experiment (results are wrong): 8 k-rows x 128 bytes per piece instead of 4 x 256
+            const int kr8 = lane >> 3, c8 = lane & 7;
 #pragma unroll
-            for (int j = 0; j < C::A_INSTR; ++j)
-                offA[j] = (unsigned)(((wv * C::A_INSTR + j) * 4 + kr) * lda + im0) * 2u + 16u * (unsigned)(p16 ^ (4 * kr));
+            for (int j = 0; j < C::A_INSTR; ++j) {
+                const int pc = wv * C::A_INSTR + j;
+                offA[j] = (unsigned)(((pc & 7) * 8 + kr8) * lda + im0 + 64 * (pc >> 3)) * 2u + 16u * (unsigned)(c8 ^ (kr8 & 7));
+            }
+#pragma unroll
+            for (int j = 0; j < C::B_INSTR; ++j) {
+                const int pc = wv * C::B_INSTR + j;
+                offB[j] = (unsigned)(((pc & 7) * 8 + kr8) * ldb + in0 + 64 * (pc >> 3)) * 2u + 16u * (unsigned)(c8 ^ (kr8 & 7));
+            }
+            (void)kr; (void)p16;
+#else
+#pragma unroll
+            for (int j = 0; j < C::A_INSTR; ++j) {
+                const int pc = wv * C::A_INSTR + j;
+                offA[j] = (unsigned)(((pc & 15) * 4 + kr) * lda + im0 + 128 * (pc >> 4)) * 2u + 16u * (unsigned)(p16 ^ (4 * kr));
+            }
 #pragma unroll
             for (int j = 0; j < C::B_INSTR; ++j)
                 offB[j] = (unsigned)(((wv * C::B_INSTR + j) * 4 + kr) * ldb + in0) * 2u + 16u * (unsigned)(p16 ^ (4 * kr));
+#endif
             stepA = (unsigned)(BK * lda) * 2u; stepB = (unsigned)(BK * ldb) * 2u;
             return;
         }
@@ -391,12 +418,17 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
         char* dstB = smem + islot * C::SLOT + C::A_BYTES + wv * (C::B_INSTR * 1024);
         if constexpr (RC) {
             const unsigned ka = (unsigned)(kcur / BK) * stepA, kbb = (unsigned)(kcur / BK) * stepB;
+#if defined(M2F_RING_EXP) && M2F_RING_EXP == 1      // experiment: no loads (consumer floor)
+            if (false)
+#endif
+            {
 #pragma unroll
             for (int j = 0; j < C::A_INSTR; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dstA + j * 1024), 16, offA[j] + ka, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < C::B_INSTR; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(dstB + j * 1024), 16, offB[j] + kbb, 0, 0, 0);
+            }
         } else {
         const unsigned kb = (unsigned)kcur * 2u;
 #if defined(M2F_RING_EXP) && M2F_RING_EXP == 1      // experiment: no loads (consumer floor)
@@ -498,7 +530,10 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
         const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
         rc_row = (8 * (g >> 1) + q) * 256 + 8 * (pp & 1);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) rc_a[i] = (((wm * (BM / 2) + i * 32 + 16 * (g & 1)) / 8 + (pp >> 1)) ^ (4 * q)) << 4;
+        for (int i = 0; i < MI; ++i) {
+            const int r0 = wm * (BM / 2) + i * 32;              // first tile row of the block: image r0 / 128, feature r0 % 128 of it
+            rc_a[i] = (r0 >> 7) * (BK * 256) + (((((r0 & 127) + 16 * (g & 1)) / 8 + (pp >> 1)) ^ (4 * q)) << 4);
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) rc_b[j] = (((wn * (BN / 2) + j * 32 + 16 * (g & 1)) / 8 + (pp >> 1)) ^ (4 * q)) << 4;
     }
@@ -570,8 +605,7 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
 #pragma unroll
                         for (int i = 0; i < MI; ++i) {
                             const ring_u32x4 w = __builtin_bit_cast(ring_u32x4, fa[buf][i]);
-                            bsum[i] += ((ring_bf16lo(w.x) + ring_bf16hi(w.x)) + (ring_bf16lo(w.y) + ring_bf16hi(w.y))) +
-                                       ((ring_bf16lo(w.z) + ring_bf16hi(w.z)) + (ring_bf16lo(w.w) + ring_bf16hi(w.w)));
+                            bsum[i] = ring_bf16x2_sum(w.w, ring_bf16x2_sum(w.z, ring_bf16x2_sum(w.y, ring_bf16x2_sum(w.x, bsum[i]))));
                         }
                     }
                     if constexpr (RELU_A) {                         // e.g. relu(cat(x, text)) of the fusion layer's Linear

@@ -195,23 +195,24 @@ def c2p_real_val_fixture(out_dir, tables):
     hook.remove()
     # seeded, learnable labels with MELD's class prior (paper/MELD.pdf Table 8: neutral 47 %, joy 17, surprise 12, anger 11, sadness 7, disgust 3, fear 3)
     g = np.random.Generator(np.random.Philox(key=[22, 0]))
-    prior = np.array([0.47, 0.12, 0.03, 0.07, 0.17, 0.03, 0.11])        # EMOTIONS order of src/dataset.py: neutral, surprise, fear, sadness, joy, disgust, anger
+    prior = np.array([0.47, 0.17, 0.07, 0.11, 0.12, 0.03, 0.03])        # label order of src/utils.py / dataset.py: neutral, joy, sadness, anger, surprise, fear, disgust
     Q = g.standard_normal((text_tab.shape[1], 7)) / np.sqrt(text_tab.shape[1])
     t = text_tab.double().numpy() @ Q
     clean = np.argmax(t / t.std() + np.log(prior), axis=1)
     # multinomial logistic regression (full-batch gradient descent, float64) on the standardised activations
-    mu, sg = feats.mean(0), feats.std(0) + 1e-6
+    mu, sg = feats.mean(0), np.full(feats.shape[1], feats.std())      # ONE scale for all features: per-feature scaling would hand
+    #                                                                     near-constant activations huge weights (rounding-noise amplifiers)
     X = (feats - mu) / sg
     W, b = np.zeros((7, X.shape[1])), np.zeros(7)
     Y = np.eye(7)[clean]
-    for _ in range(400):
+    for _ in range(200):                                                 # (a partial fit of the clean labels, margins of order 1)
         z = X @ W.T + b
         z -= z.max(1, keepdims=True)
         P = np.exp(z)
         P /= P.sum(1, keepdims=True)
         G = (P - Y) / n_rows
-        W -= 1.0 * (G.T @ X + 1e-3 * W)
-        b -= 1.0 * G.sum(0)
+        W -= 0.3 * (G.T @ X + 1e-2 * W)
+        b -= 0.3 * G.sum(0)
     W32 = (W / sg).astype(np.float32)
     b32 = (b - (W / sg) @ mu).astype(np.float32)
     sd = dict(sd)

@@ -112,3 +112,43 @@ def digest_vector(shape, seed: int, idx: int) -> torch.Tensor:
 
 
 CLASS_WEIGHTS = torch.tensor([0.30, 1.20, 2.10, 1.30, 1.20, 5.30, 5.20], dtype=torch.float32)
+
+
+# The reference's shipped model section (/root/reference/src/config.yaml:31-54, verbatim) = C2' of SURVEY 8
+C2P_MODEL = {
+    "dropout": 0.4,
+    "AUDIO": {"enabled": True, "embedding_size": 768, "n_head": 8, "n_transformers": 1, "n_encoder_layers": 6},
+    "TEXT": {"enabled": True, "embedding_size": 768, "n_head": 8, "n_transformers": 1, "n_encoder_layers": 6},
+    "FAM": {"enabled": True, "embedding_size": 768, "n_head": 8, "n_layers": 5},
+    "CLASSIFIER": {"hidden_size": 768, "output_size": 7, "n_layers": 2},
+}
+
+
+def c2p_real_val_case(fx):
+    """The shipped-depth case on all 1,108 real val.pkl rows (make_golden.py::c2p_real_val_fixture):
+    -> (model cfg, state_dict, batches) with batches = [(text [B,L,768], audio [B,L,768], key_pad [B,L], emotion [B,L], row_index [B,L])]
+    in the validation loader's order (32 dialogues per batch, last one partial); row_index maps a slot to its row of
+    fx['logits'] (-1 on pads).  Weights: make_state_dict, with the fitted last Linear the fixture carries."""
+    cfg = C2P_MODEL
+    sd = make_state_dict(cfg)
+    names = list(sd.keys())
+    sd[names[-2]] = torch.from_numpy(np.ascontiguousarray(fx["last_weight"]))
+    sd[names[-1]] = torch.from_numpy(np.ascontiguousarray(fx["last_bias"]))
+    text_tab, audio_tab = torch.from_numpy(fx["text_rows"]), torch.from_numpy(fx["audio_rows"])
+    labels = torch.from_numpy(fx["labels"])
+    lens = [int(x) for x in fx["lengths"]]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    batches = []
+    for b0 in range(0, len(lens), 32):
+        ls, ss = lens[b0: b0 + 32], starts[b0: b0 + 32]
+        B, L = len(ls), max(ls)
+        text, audio = torch.zeros(B, L, text_tab.shape[1]), torch.zeros(B, L, audio_tab.shape[1])
+        emo = torch.full((B, L), -1, dtype=torch.int64)
+        rows = torch.full((B, L), -1, dtype=torch.int64)
+        for i, (n, s0) in enumerate(zip(ls, ss)):
+            s0 = int(s0)
+            text[i, :n], audio[i, :n] = text_tab[s0: s0 + n], audio_tab[s0: s0 + n]
+            emo[i, :n] = labels[s0: s0 + n]
+            rows[i, :n] = torch.arange(s0, s0 + n)
+        batches.append((text, audio, emo == -1, emo, rows))
+    return cfg, sd, batches

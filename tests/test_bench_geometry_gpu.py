@@ -48,7 +48,7 @@ def _oracle(workload):
     return _ORACLE[workload]
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c2p"])
 def test_bench_plan_fp32_matches_oracle(workload):
     cfg, sd, batch = _setup(workload)
     ref_logits, ref_loss, ref_grads = _oracle(workload)
@@ -75,7 +75,7 @@ def test_bench_plan_fp32_matches_oracle(workload):
         assert float((g - r).abs().max()) <= 0.1 * float(r.abs().max()) + 2e-7, (k, float((g - r).abs().max()), float(r.abs().max()))
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c2p"])
 def test_bench_plan_bf16_within_stated_tolerance(workload):
     cfg, sd, batch = _setup(workload)
     ref_logits, ref_loss, ref_grads = _oracle(workload)
@@ -121,3 +121,50 @@ def test_bf16_adam_trajectory_tracks_fp32():
     assert f[-1] < f[0] - 0.05, "the fp32 run must actually learn on the batch"
     assert np.max(np.abs(b - f) / np.abs(f)) < 0.03, (f, b)
     assert abs((b[0] - b[-1]) - (f[0] - f[-1])) < 0.10 * (f[0] - f[-1])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_shipped_depth_on_all_real_validation_rows(golden_dir, precision):
+    """tests/golden/c2p_real_val.npz (written by the REAL reference, make_golden.py): the shipped config.yaml model at full depth
+    on all 1,108 matched rows of the real val.pkl embeddings, evaluated the way src/train.py:245-272 validates - eval forward per
+    batch of 32 dialogues (lengths 1..33: three L buckets, a partial last batch), per-batch accuracy / weighted-F1, plain mean.
+    fp32 mode: every logit within 1e-3 of the reference, every prediction equal, hence the SAME scores.  bf16 mode (the mode
+    the headline number runs in): predictions may flip only where the reference itself is within rounding of a tie - weighted-F1
+    within +-0.2 points and accuracy within +-0.3 points of the reference's (north_star's MELD target, on the only real
+    embeddings the container holds)."""
+    import os
+    from sklearn.metrics import accuracy_score, f1_score
+    fx = np.load(os.path.join(golden_dir, "c2p_real_val.npz"))
+    cfg, sd, batches = synth.c2p_real_val_case(fx)
+    m = M2FNet(cfg, precision=precision)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0").eval()
+    ref = torch.from_numpy(fx["logits"])
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)
+    worst, agree, n, losses, accs, f1s = 0.0, 0, 0, [], [], []
+    with torch.inference_mode():
+        for text, audio, key_pad, emotion, rows in batches:
+            lg = m(text.cuda(), audio.cuda(), key_pad.cuda()).cpu()
+            valid = ~key_pad
+            worst = max(worst, (lg[valid] - ref[rows[valid]]).abs().max().item())
+            agree += int((lg[valid].argmax(1) == ref[rows[valid]].argmax(1)).sum())
+            n += int(valid.sum())
+            losses.append(crit(lg.permute(0, 2, 1), emotion).item())
+            p, t = lg.argmax(2)[valid].numpy(), emotion[valid].numpy()
+            accs.append(accuracy_score(t, p))
+            f1s.append(f1_score(t, p, average="weighted"))
+    acc, f1, loss = float(np.mean(accs)), float(np.mean(f1s)), float(np.mean(losses))
+    print(f"{precision}: max |dlogit| {worst:.2e}, predictions equal {agree}/{n}, val loss {loss:.5f} (ref {float(fx['val_loss']):.5f}), "
+          f"acc {100 * acc:.3f} (ref {100 * float(fx['acc']):.3f}), wF1 {100 * f1:.3f} (ref {100 * float(fx['f1']):.3f})")
+    assert n == 1108
+    if precision == "fp32":
+        assert worst < 1e-3, worst
+        assert agree == n
+        assert np.allclose(accs, fx["acc_per_batch"], atol=1e-12) and np.allclose(f1s, fx["f1_per_batch"], atol=1e-12)
+        assert abs(loss - float(fx["val_loss"])) < 1e-4
+    else:
+        assert worst < 6e-2, worst                           # logits of standard deviation 2.0: 3 % of it
+        assert agree >= 0.99 * n, agree
+        assert abs(f1 - float(fx["f1"])) <= 0.002, (f1, float(fx["f1"]))
+        assert abs(acc - float(fx["acc"])) <= 0.003, (acc, float(fx["acc"]))
+        assert abs(loss - float(fx["val_loss"])) < 2e-2

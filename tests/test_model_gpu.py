@@ -210,13 +210,15 @@ def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monke
 
 
 @pytest.mark.parametrize("name,tile", [("c2_slice", "64"), ("c2_slice", "128"), ("c2_slice", "129"), ("c2_slice", "256"),
-                                       ("tiny_ragged", "256"), ("tiny_shared_norm", "256"), ("tiny_no_fam", "129")])
+                                       ("tiny_ragged", "256"), ("tiny_shared_norm", "256"), ("tiny_no_fam", "129"),
+                                       ("c2_slice", "131"), ("c3_slice_l16", "131"), ("tiny_ragged", "131"), ("tiny_odd_heads", "131")])
 def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, name, tile, monkeypatch):
     """The weight-gradient table launch runs by default in the ring form on the row-major bf16 shadows (130: no token-
     transposed copies; the kernel sums the bias gradients from the bf16 operands) and exists as register-staged 64x64,
     128x128 and 256x128 builds and a ring form (129) on token-transposed copies, whose transposing launch sums the bias
     gradients in fp32 (M2F_TABLE_TILE, read when a plan is built).  Same operands and k order for the weights: they agree
-    to fp32 summation noise; the bias gradients to the bf16 rounding of their summands."""
+    to fp32 summation noise; the bias gradients to the bf16 rounding of their summands.  131 = the row-major ring form with
+    256 x 128 tiles (two 128-feature images per operand row block)."""
     fx = _load(golden_dir, name)
     cfg, text, audio, key_pad, emotion = _inputs(name, fx)      # the tiny cases: widths below one tile, ragged token counts
     batch = (text, audio, key_pad, emotion)
@@ -233,6 +235,22 @@ def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, name, tile, 
             assert (g_variant[k] - ref).abs().max().item() <= tol * scale, k
             checked_bias += summed_from_bf16
     assert checked_bias >= (10 if name == "c2_slice" else 4)
+
+
+@pytest.mark.parametrize("name", ["c2_slice", "c3_slice_l16", "tiny_shared_norm"])
+def test_weight_gradient_table_walk_orders_are_bit_identical(golden_dir, name, monkeypatch):
+    """The weight-gradient table launch deals its tiles to the workgroups as per-workgroup lists (m2f_gemm_table_walk): by
+    default every XCD walks its own problems in 8 x 4 super-tiles, M2F_TABLE_WALK=0 keeps the order of the tile list.  A tile
+    is the same computation wherever it runs: every gradient must come out bit for bit the same."""
+    fx = _load(golden_dir, name)
+    cfg, text, audio, key_pad, emotion = _inputs(name, fx)
+    batch = (text, audio, key_pad, emotion)
+    g_default = _train_grads(cfg, "bf16", batch)
+    monkeypatch.setenv("M2F_TABLE_WALK", "0")
+    g_list = _train_grads(cfg, "bf16", batch)
+    monkeypatch.delenv("M2F_TABLE_WALK")
+    for k, ref in g_default.items():
+        assert torch.equal(g_list[k], ref), k
 
 
 def test_live_oracle_full_size_properties():

@@ -103,6 +103,30 @@ def test_oracle_adam_three_steps(golden_dir, name):
     assert (logits - torch.from_numpy(fx["adam3_logits_eval"])).abs()[~key_pad].max() < 2e-4
 
 
+def test_oracle_shipped_depth_on_all_real_validation_rows(golden_dir):
+    """c2p_real_val: the reference's config.yaml model verbatim (6 + 6 encoder layers, 5 FAM layers, 768^3) on ALL 1,108 matched
+    rows of the real val.pkl embeddings, in the validation loader's batches: the oracle reproduces the reference's logits,
+    every prediction, and the validation rule of src/train.py:245-272 (per-batch loss / accuracy / weighted-F1, plain mean)."""
+    from sklearn.metrics import accuracy_score, f1_score
+    fx = _load(golden_dir, "c2p_real_val")
+    cfg, sd, batches = synth.c2p_real_val_case(fx)
+    ref = torch.from_numpy(fx["logits"])
+    losses, accs, f1s, worst = [], [], [], 0.0
+    for bi, (text, audio, key_pad, emotion, rows) in enumerate(batches):
+        lg = O.forward(sd, cfg, text, audio, key_pad)
+        valid = ~key_pad
+        worst = max(worst, (lg[valid] - ref[rows[valid]]).abs().max().item())
+        assert torch.equal(lg[valid].argmax(1), ref[rows[valid]].argmax(1))
+        losses.append(float(O.cross_entropy(lg, emotion, None, 0.1)))
+        p, t = lg.argmax(2)[valid].numpy(), emotion[valid].numpy()
+        accs.append(accuracy_score(t, p))
+        f1s.append(f1_score(t, p, average="weighted"))
+    assert worst < 1e-4, worst
+    assert np.allclose(losses, fx["loss_per_batch"], atol=2e-5)
+    assert np.allclose(accs, fx["acc_per_batch"], atol=1e-12) and np.allclose(f1s, fx["f1_per_batch"], atol=1e-12)
+    assert abs(np.mean(f1s) - float(fx["f1"])) < 1e-12 and abs(np.mean(accs) - float(fx["acc"])) < 1e-12
+
+
 def test_oracle_cross_entropy_vs_torch():
     g = torch.Generator().manual_seed(3)
     logits = torch.randn(6, 9, 7, generator=g) * 2

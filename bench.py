@@ -168,6 +168,9 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         plan.set_inputs(text, audio, mask, emotion)
 
         def one_step():
+            # bf16 mode, N = 1: the fused Adam kernel also writes the bf16 parameter shadows, the forward then skips its parameter
+            # casts (the engine compares the parameters' version counters: any other write to them brings the casts back)
+            plan.params_fresh(eng.shadows_fresh())
             plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
             stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
 

@@ -83,6 +83,22 @@ int64_t m2f_workspace_bytes_packed(const m2f_config* cfg, int B, int L, int T, i
 m2f_plan* m2f_plan_create_packed(const m2f_config* cfg, int B, int L, int T, int precision, int train,
                                  float* params, float* grads, void* workspace, int64_t workspace_bytes,
                                  uint32_t* rng_state);
+/* SHARED PARAMETER SHADOWS (bf16 mode).  The GEMMs stage bf16 copies of every 2-D parameter (W [rows][pad8(cols)] and W^T
+ * [cols][pad8(rows)]); a plan of m2f_plan_create keeps its own copies in its workspace and refreshes them with cast launches at
+ * the head of every forward.  With m2f_plan_create_shared all plans of a model use ONE caller-owned buffer of
+ * m2f_param_shadow_elems(cfg) uint16 (256-byte aligned; initialise it once with m2f_param_shadow_init), and an optimizer step
+ * through m2f_adam_step_shadowed writes the shadows of the parameters it has just updated.  The caller then declares them
+ * current with m2f_plan_params_fresh(plan, 1) and the forward skips its parameter casts (2 x 87 us of 2.7 ms at C3); after
+ * any OTHER write to the parameters (load_state_dict, a foreign optimizer) it must pass 0 again - a forward that ran the casts
+ * leaves the shadows current, too.  T = 0: padded plan, T > 0: packed plan of T token rows (as m2f_plan_create_packed).
+ * No counterpart in the reference: torch keeps no low-precision parameter copies (src/train.py:56,231 is all it does). */
+int64_t m2f_param_shadow_elems(const m2f_config* cfg);
+int m2f_param_shadow_init(const m2f_config* cfg, uint16_t* param_shadow, m2f_stream_t stream);
+int64_t m2f_workspace_bytes_shared(const m2f_config* cfg, int B, int L, int T, int train);
+m2f_plan* m2f_plan_create_shared(const m2f_config* cfg, int B, int L, int T, int precision, int train,
+                                 float* params, float* grads, void* workspace, int64_t workspace_bytes,
+                                 uint32_t* rng_state, uint16_t* param_shadow);
+int m2f_plan_params_fresh(m2f_plan* plan, int fresh);
 void m2f_plan_destroy(m2f_plan* plan);
 void* m2f_plan_buffer(m2f_plan* plan, int which);
 int m2f_plan_num_launches(m2f_plan* plan, int phase);   /* 0 fwd, 1 loss, 2 bwd */
@@ -148,6 +164,13 @@ int m2f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int m2f_adam_step_g16(float* params, const uint16_t* grads_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       const float* grad_scale_ptr, m2f_stream_t stream);
+
+/* The same optimizer step over the WHOLE flat buffers of a model (cfg gives the tensor table), walking the 2-D parameters in
+ * 64 x 64 tiles so that the kernel also writes their bf16 shadows (W and W^T) into the shared buffer of m2f_param_shadow_init:
+ * 28 B of optimizer traffic + 4 B of shadow writes per parameter instead of 28 B + a separate 8 B cast pass per forward. */
+int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                           uint16_t* param_shadow, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           const float* grad_scale_ptr, m2f_stream_t stream);
 
 /* ---- in-loop text encoder (BASELINE config C5) -------------------------------------------------
  * The reference computes its text embeddings with transformers' RobertaModel (src/feature_extractors/text/model.py:16-21,

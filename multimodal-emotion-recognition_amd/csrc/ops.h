@@ -277,6 +277,18 @@ hipError_t m2f_launch_adam(float* p, const void* g, int g_is_bf16, float* m, flo
                            float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
                            hipStream_t stream);
 
+// Fused Adam + parameter-shadow refresh (bf16 mode, single process): the same update as m2f_launch_adam, walked matrix by matrix
+// in 64x64 tiles so that the kernel that has the new fp32 parameter in registers also writes its bf16 shadows - W [rows][pad8(cols)]
+// and W^T [cols][pad8(rows)] through an LDS tile - which the forward / input-gradient GEMMs stage from.  The cast launches at
+// the head of the forward (8 B of traffic per parameter, 2 x 87 us at C3) disappear.  Items live in device memory:
+// rows > 0: a 2-D parameter (tiles of 64 x 64); rows == 0: `cols` consecutive elements (1-D parameters incl. their pads; tiles
+// of 4096 elements).
+struct AdamItem { long long off, soff, soff_t; int rows, cols, tile_begin, tiles_c; };
+#define M2F_ADAM_MAX_ITEMS 1024
+hipError_t m2f_launch_adam_shadowed(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items,
+                                    const int* tile_begin, int n_items, int total_tiles, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, int step, const float* grad_scale_ptr, hipStream_t stream);
+
 #ifdef __HIPCC__
 // shadow address of a workspace element, or null (no shadows / pointer outside the workspace, e.g. the gradient buffer)
 __device__ __forceinline__ uint16_t* m2f_shadow_of(const ShadowMap& sh, const float* p) {

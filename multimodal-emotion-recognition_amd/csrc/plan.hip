@@ -238,7 +238,13 @@ struct m2f_plan {
     // bf16 mode: shadows of the workspace activations (same element index) and of the 2-D parameters (padded rows)
     ShadowMap sh = {nullptr, nullptr, 0};
     uint16_t* wshadow = nullptr;
-    std::vector<CastBatch> casts;        // parameters + input staging -> bf16, at the start of every forward
+    std::vector<CastBatch> param_casts;  // bf16 mode, at the start of a forward: every 2-D parameter -> its W and W^T shadows ...
+    std::vector<CastBatch> input_casts;  // ... and the two input staging buffers -> their activation shadows
+    // The parameter shadows may live OUTSIDE the plan (m2f_plan_create_shared: one buffer shared by all plans of a model) and be
+    // kept current by the optimizer itself (m2f_adam_step_shadowed); the caller then declares them fresh
+    // (m2f_plan_params_fresh) and the forward skips the parameter casts.
+    uint16_t* ext_wshadow = nullptr;
+    bool params_fresh = false;
     std::vector<Launch> fwd, bwd;
     // deferred weight-gradient launches, run after the backward chain on the same stream.  (Overlapping them with the
     // chain on a second stream was measured SLOWER inside the captured graph: every fork costs the chain a 12-16 us
@@ -261,7 +267,7 @@ struct m2f_plan {
     size_t ws_used = 0;
     // graph cache for m2f_step
     hipGraphExec_t gexec = nullptr;
-    float g_ls = 0.f; int g_cw = -1, g_norm = -1;
+    float g_ls = 0.f; int g_cw = -1, g_norm = -1, g_fresh = -1;
     bool warmed = false;          // one eager step (sets kernel attributes) before the first capture
     ~m2f_plan() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -1093,7 +1099,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
     bld.ar.off = (bld.ar.off + 255) / 256 * 256;
     const size_t ws_floats = bld.ar.off / 4;
     uint16_t* shadow = bld.ar.alloc<uint16_t>(ws_floats);
-    uint16_t* wshadow = bld.ar.alloc<uint16_t>(P.pm.shadow_elems + 64);
+    uint16_t* wshadow = P.ext_wshadow ? P.ext_wshadow : bld.ar.alloc<uint16_t>(P.pm.shadow_elems + 64);
     // ---- weight-gradient table (bf16 mode): token-transposed operand copies, problem table, tile map ------------------
     std::vector<TransItem> titems;
     std::vector<uint16_t> tblock;
@@ -1273,13 +1279,15 @@ int build_plan(m2f_plan& P, char* ws_base) {
         // casts at the start of a forward: every 2-D parameter into its padded shadow, then the two input buffers
         CastBatch cb;
         memset(&cb, 0, sizeof(cb));
-        auto flush = [&]() { if (cb.count) { P.casts.push_back(cb); memset(&cb, 0, sizeof(cb)); } };
+        std::vector<CastBatch>* dst = &P.param_casts;
+        auto flush = [&]() { if (cb.count) { dst->push_back(cb); memset(&cb, 0, sizeof(cb)); } };
         for (const ParamMap::Mat& m : P.pm.mats) {
             cb.it[cb.count++] = {P.params + m.off, wshadow + m.soff, m.rows, m.cols, m.cols, (m.cols + 7) & ~7,
                                  wshadow + m.soff_t, (m.rows + 7) & ~7};
             if (cb.count == M2F_CAST_MAX_ITEMS) flush();
         }
         flush();
+        dst = &P.input_casts;
         if (c.text_enabled) {
             const int dp = Builder::pad8(c.d_text);
             float* x = static_cast<float*>(P.bufs[M2F_BUF_TEXT]);
@@ -1450,16 +1458,21 @@ static m2f_plan* plan_new(const m2f_config* cfg, int B, int L, int precision, in
     return p;
 }
 
-static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int train, int T_packed);
+static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int train, int T_packed, bool shared = false);
 int64_t m2f_workspace_bytes(const m2f_config* cfg, int B, int L, int train) { return workspace_bytes_impl(cfg, B, L, train, 0); }
 int64_t m2f_workspace_bytes_packed(const m2f_config* cfg, int B, int L, int T, int train) {
     if (T < 1) { fail("packed plan: T >= 1 required"); return -1; }
     return workspace_bytes_impl(cfg, B, L, train, T);
 }
-static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int train, int T_packed) {
+int64_t m2f_workspace_bytes_shared(const m2f_config* cfg, int B, int L, int T, int train) {
+    if (T < 0) { fail("m2f_workspace_bytes_shared: T >= 0 required (0 = padded plan)"); return -1; }
+    return workspace_bytes_impl(cfg, B, L, train, T, true);
+}
+static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int train, int T_packed, bool shared) {
     m2f_plan* p = plan_new(cfg, B, L, M2F_F32, train, T_packed);
     if (!p) return -1;
     p->params = nullptr; p->grads = nullptr;
+    if (shared) p->ext_wshadow = reinterpret_cast<uint16_t*>(256);        // sizing pass: the plan will not hold parameter shadows
     build_plan(*p, nullptr);
     const int64_t n = (int64_t)p->ws_used + 4096;
     delete p;
@@ -1467,7 +1480,13 @@ static int64_t workspace_bytes_impl(const m2f_config* cfg, int B, int L, int tra
 }
 
 static m2f_plan* plan_create_impl(const m2f_config* cfg, int B, int L, int T_packed, int precision, int train, float* params,
-                                  float* grads, void* workspace, int64_t workspace_bytes, uint32_t* rng_state);
+                                  float* grads, void* workspace, int64_t workspace_bytes, uint32_t* rng_state, uint16_t* param_shadow = nullptr);
+m2f_plan* m2f_plan_create_shared(const m2f_config* cfg, int B, int L, int T, int precision, int train, float* params, float* grads,
+                                 void* workspace, int64_t workspace_bytes, uint32_t* rng_state, uint16_t* param_shadow) {
+    if (T < 0) { fail("m2f_plan_create_shared: T >= 0 required (0 = padded plan)"); return nullptr; }
+    if (!param_shadow || (reinterpret_cast<uintptr_t>(param_shadow) & 255)) { fail("m2f_plan_create_shared: param_shadow must be a 256-byte aligned device buffer of m2f_param_shadow_elems() uint16"); return nullptr; }
+    return plan_create_impl(cfg, B, L, T, precision, train, params, grads, workspace, workspace_bytes, rng_state, param_shadow);
+}
 m2f_plan* m2f_plan_create(const m2f_config* cfg, int B, int L, int precision, int train, float* params, float* grads,
                           void* workspace, int64_t workspace_bytes, uint32_t* rng_state) {
     return plan_create_impl(cfg, B, L, 0, precision, train, params, grads, workspace, workspace_bytes, rng_state);
@@ -1478,9 +1497,10 @@ m2f_plan* m2f_plan_create_packed(const m2f_config* cfg, int B, int L, int T, int
     return plan_create_impl(cfg, B, L, T, precision, train, params, grads, workspace, workspace_bytes, rng_state);
 }
 static m2f_plan* plan_create_impl(const m2f_config* cfg, int B, int L, int T_packed, int precision, int train, float* params,
-                                  float* grads, void* workspace, int64_t workspace_bytes, uint32_t* rng_state) {
+                                  float* grads, void* workspace, int64_t workspace_bytes, uint32_t* rng_state, uint16_t* param_shadow) {
     m2f_plan* p = plan_new(cfg, B, L, precision, train, T_packed);
     if (!p) return nullptr;
+    p->ext_wshadow = param_shadow;
     if (!params || !workspace) { fail("params / workspace must not be NULL"); delete p; return nullptr; }
     if (train && !grads) { fail("train plan needs a gradient buffer"); delete p; return nullptr; }
     if (p->use_dropout && !rng_state) { fail("dropout > 0 in train mode needs an rng_state"); delete p; return nullptr; }
@@ -1490,7 +1510,7 @@ static m2f_plan* plan_create_impl(const m2f_config* cfg, int B, int L, int T_pac
     }
     p->params = params; p->grads = grads; p->rng = rng_state;
     {   // size the workspace with a dry build BEFORE anything is written into it
-        const int64_t need = workspace_bytes_impl(cfg, B, L, train, T_packed);
+        const int64_t need = workspace_bytes_impl(cfg, B, L, train, T_packed, param_shadow != nullptr);
         if (need < 0 || need > workspace_bytes) {
             fail("workspace too small: need " + std::to_string(need) + " bytes");
             delete p;
@@ -1514,6 +1534,87 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
 }
 
 int m2f_plan_persistent(m2f_plan* plan) { return plan ? (plan->mfwd.on ? 1 : 0) | (plan->mbwd.on ? 2 : 0) : 0; }
+
+int m2f_plan_params_fresh(m2f_plan* plan, int fresh) {
+    if (!plan) return fail("m2f_plan_params_fresh: NULL plan (destroyed?)");
+    if (fresh && !plan->ext_wshadow) return fail("m2f_plan_params_fresh: only plans created with m2f_plan_create_shared can skip their parameter casts");
+    plan->params_fresh = fresh != 0;
+    return 0;
+}
+
+// ---- parameter shadows shared by the plans of one model + the optimizer that keeps them current -------------------------
+namespace {
+constexpr int64_t ADAM_TABLE_BYTES = 64 * 1024;          // behind the shadows: AdamItem[n] | int tile_begin[n + 1]
+struct AdamTable { std::vector<AdamItem> items; std::vector<int> tile_begin; int total_tiles = 0; size_t shadow_elems = 0; };
+int adam_table(const m2f_config& cfg, AdamTable& t) {
+    ParamMap pm;
+    if (build_param_map(cfg, pm)) return 1;
+    t.shadow_elems = pm.shadow_elems + 64;
+    size_t mi = 0;
+    for (size_t i = 0; i < pm.offsets.size(); ++i) {
+        AdamItem it; memset(&it, 0, sizeof(it));
+        it.off = pm.offsets[i]; it.tile_begin = t.total_tiles;
+        if (mi < pm.mats.size() && pm.mats[mi].off == (size_t)pm.offsets[i]) {
+            const ParamMap::Mat& m = pm.mats[mi++];
+            it.rows = m.rows; it.cols = m.cols; it.soff = (long long)m.soff; it.soff_t = (long long)m.soff_t;
+            it.tiles_c = (m.cols + 63) / 64;
+            t.total_tiles += ((m.rows + 63) / 64) * it.tiles_c;
+        } else {
+            const int64_t next = i + 1 < pm.offsets.size() ? pm.offsets[i + 1] : (int64_t)pm.total;
+            it.rows = 0; it.cols = (int)(next - pm.offsets[i]);            // the tensor and its pad up to the next one (multiples of 64)
+            it.tiles_c = 1;
+            t.total_tiles += (it.cols + 4095) / 4096;
+        }
+        t.tile_begin.push_back(it.tile_begin);
+        t.items.push_back(it);
+    }
+    t.tile_begin.push_back(t.total_tiles);
+    if (mi != pm.mats.size()) return fail("adam_table: parameter map walk lost a matrix");
+    if (t.items.size() > M2F_ADAM_MAX_ITEMS || t.items.size() * sizeof(AdamItem) + t.tile_begin.size() * sizeof(int) > (size_t)ADAM_TABLE_BYTES)
+        return fail("too many parameter tensors for the fused optimizer table");
+    return 0;
+}
+}  // namespace
+
+int64_t m2f_param_shadow_elems(const m2f_config* cfg) {
+    AdamTable t;
+    if (adam_table(*cfg, t)) return -1;
+    return (int64_t)((t.shadow_elems + 127) / 128 * 128) + ADAM_TABLE_BYTES / 2;
+}
+
+int m2f_param_shadow_init(const m2f_config* cfg, uint16_t* param_shadow, m2f_stream_t stream) {
+    AdamTable t;
+    if (adam_table(*cfg, t)) return 1;
+    if (!param_shadow || (reinterpret_cast<uintptr_t>(param_shadow) & 255)) return fail("m2f_param_shadow_init: 256-byte aligned buffer required");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t sh = (t.shadow_elems + 127) / 128 * 128;
+    M2F_HIP(hipMemsetAsync(param_shadow, 0, sh * sizeof(uint16_t) + ADAM_TABLE_BYTES, s));      // the pad columns of the shadows stay zero for good
+    char* tab = reinterpret_cast<char*>(param_shadow + sh);
+    M2F_HIP(hipMemcpyAsync(tab, t.items.data(), t.items.size() * sizeof(AdamItem), hipMemcpyHostToDevice, s));
+    M2F_HIP(hipMemcpyAsync(tab + t.items.size() * sizeof(AdamItem), t.tile_begin.data(), t.tile_begin.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    M2F_HIP(hipStreamSynchronize(s));                           // (the host vectors go out of scope)
+    return 0;
+}
+
+int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                           uint16_t* param_shadow, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           const float* grad_scale_ptr, m2f_stream_t stream) {
+    thread_local m2f_config cached_cfg;
+    thread_local AdamTable cached;
+    thread_local bool have = false;
+    if (!have || memcmp(&cached_cfg, cfg, sizeof(m2f_config)) != 0) {
+        AdamTable t;
+        if (adam_table(*cfg, t)) return 1;
+        cached = t; cached_cfg = *cfg; have = true;
+    }
+    const size_t sh = (cached.shadow_elems + 127) / 128 * 128;
+    const char* tab = reinterpret_cast<const char*>(param_shadow + sh);
+    M2F_HIP(m2f_launch_adam_shadowed(params, grads, exp_avg, exp_avg_sq, param_shadow, reinterpret_cast<const AdamItem*>(tab),
+                                     reinterpret_cast<const int*>(tab + cached.items.size() * sizeof(AdamItem)), (int)cached.items.size(),
+                                     cached.total_tiles, lr, beta1, beta2, eps, weight_decay, step, grad_scale_ptr,
+                                     static_cast<hipStream_t>(stream)));
+    return 0;
+}
 
 int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
     if (!plan || !out8) return fail("m2f_plan_status: NULL plan (destroyed?) or output");
@@ -1540,16 +1641,19 @@ int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
 
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (!plan) return -1;
-    if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + plan->casts.size());
+    if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + (plan->params_fresh ? 0 : plan->param_casts.size()) + plan->input_casts.size());
     if (phase == 1) return 2;
     return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() + plan->wg_casts.size() : plan->wg.size()) + plan->lnred.size());
 }
 
 static int do_forward(m2f_plan& P, hipStream_t s) {
-    for (const CastBatch& cb : P.casts) {                      // bf16 mode only: refresh the parameter / input shadows
-        if (g_prof) g_prof->begin(10, 0.0);
-        M2F_HIP(m2f_launch_cast(cb, s));
-        if (g_prof) g_prof->end();
+    for (const std::vector<CastBatch>* cl : {&P.param_casts, &P.input_casts}) {      // bf16 mode only: refresh the parameter / input shadows
+        if (cl == &P.param_casts && P.params_fresh) continue;                         // (the optimizer wrote them: m2f_adam_step_shadowed)
+        for (const CastBatch& cb : *cl) {
+            if (g_prof) g_prof->begin(10, 0.0);
+            M2F_HIP(m2f_launch_cast(cb, s));
+            if (g_prof) g_prof->end();
+        }
     }
     if (P.mfwd.on) return run_mega(P.mfwd, 11, s);
     return run_launches(P, P.fwd, s);
@@ -1584,7 +1688,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!P.train) return fail("m2f_step needs a train plan");
     if (!use_graph || !P.warmed) { P.warmed = true; return step_body(P, label_smoothing, use_class_weights, normalise, s); }
-    if (P.gexec && (P.g_ls != label_smoothing || P.g_cw != use_class_weights || P.g_norm != normalise)) {
+    if (P.gexec && (P.g_ls != label_smoothing || P.g_cw != use_class_weights || P.g_norm != normalise || P.g_fresh != (int)P.params_fresh)) {
         (void)hipGraphExecDestroy(P.gexec);
         P.gexec = nullptr;
     }
@@ -1598,7 +1702,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
         e = hipGraphInstantiate(&P.gexec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { P.gexec = nullptr; return hipfail(e, "hipGraphInstantiate"); }
-        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise;
+        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise; P.g_fresh = (int)P.params_fresh;
     }
     M2F_HIP(hipGraphLaunch(P.gexec, s));
     return 0;

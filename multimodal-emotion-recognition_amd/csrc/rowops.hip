@@ -429,6 +429,128 @@ __global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, co
     }
 }
 
+// Adam update of four consecutive elements (registers in, registers out) - the arithmetic of m2f_adam_kernel
+__device__ __forceinline__ void adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float gs, float lr_bc1, float beta1,
+                                      float beta2, float eps, float wd, float inv_sqrt_bc2) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gr = gg[e] * gs + wd * pp[e];                  // coupled L2 (Adam, not AdamW)
+        mm[e] = beta1 * mm[e] + (1.f - beta1) * gr;
+        vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+        const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+        pp[e] -= lr_bc1 * (mm[e] / denom);
+    }
+}
+
+// see ops.h (AdamItem).  Persistent 1-D grid over the tile list; tile -> item by bisection of the prefix array (kept in LDS).
+__global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, uint16_t* __restrict__ sh,
+                                                              const AdamItem* __restrict__ items, const int* __restrict__ tile_begin,
+                                                              int n_items, int total_tiles, float lr_bc1, float beta1, float beta2,
+                                                              float eps, float wd, float inv_sqrt_bc2, const float* __restrict__ gs_ptr) {
+    __shared__ float tile[64][65];
+    __shared__ int tb[M2F_ADAM_MAX_ITEMS + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= n_items; i += 256) tb[i] = tile_begin[i];
+    __syncthreads();
+    const float gs = gs_ptr ? 1.0f / *gs_ptr : 1.0f;
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        int lo = 0, hi = n_items - 1;                               // last item whose first tile is <= t (block-uniform)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tb[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const AdamItem it = items[lo];
+        const int tl = t - tb[lo];
+        if (it.rows == 0) {                                         // 1-D parameter: 4096 consecutive elements per tile
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long idx = (long long)tl * 4096 + q * 1024 + tid * 4;
+                if (idx < it.cols) {
+                    const long long o = it.off + idx;
+                    f32x4 pp = *reinterpret_cast<const f32x4*>(p + o);
+                    const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o));
+                    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + o));
+                    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + o));
+                    adam4(pp, gg, mm, vv, gs, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2);
+                    *reinterpret_cast<f32x4*>(p + o) = pp;
+                    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + o));
+                    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + o));
+                }
+            }
+            continue;
+        }
+        const int rows = it.rows, cols = it.cols, ldd = (cols + 7) & ~7, ldt = (rows + 7) & ~7;
+        const int r0 = (tl / it.tiles_c) << 6, c0 = (tl % it.tiles_c) << 6;
+        const int lr = tid >> 4, c = 4 * (tid & 15), gc = c0 + c;
+        const bool vec = (cols & 3) == 0;                           // then every 4-column group is whole and 16-byte aligned
+        f32x4 pp[4], gg[4], mm[4], vv[4];
+        bool in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                               // all loads of the tile first, then the arithmetic
+            const int gr = r0 + lr + 16 * i;
+            in[i] = gr < rows && gc < cols;
+            const long long o = it.off + (long long)(in[i] ? gr : 0) * cols + (in[i] ? gc : 0);
+            if (vec) {
+                pp[i] = *reinterpret_cast<const f32x4*>(p + o);
+                gg[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o));
+                mm[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + o));
+                vv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + o));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long oe = o + ((in[i] && gc + e < cols) ? e : 0);
+                    pp[i][e] = p[oe]; gg[i][e] = g[oe]; mm[i][e] = m[oe]; vv[i][e] = v[oe];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 16 * i, gr = r0 + r;
+            adam4(pp[i], gg[i], mm[i], vv[i], gs, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][c + e] = (in[i] && gc + e < cols) ? pp[i][e] : 0.f;
+            if (in[i]) {
+                const long long o = it.off + (long long)gr * cols + gc;
+                uint16_t* q = sh + it.soff + (long long)gr * ldd + gc;
+                if (vec) {
+                    *reinterpret_cast<f32x4*>(p + o) = pp[i];
+                    __builtin_nontemporal_store(mm[i], reinterpret_cast<f32x4*>(m + o));
+                    __builtin_nontemporal_store(vv[i], reinterpret_cast<f32x4*>(v + o));
+                    uint2 w;
+                    w.x = (uint32_t)m2f_bf16_bits(pp[i][0]) | ((uint32_t)m2f_bf16_bits(pp[i][1]) << 16);
+                    w.y = (uint32_t)m2f_bf16_bits(pp[i][2]) | ((uint32_t)m2f_bf16_bits(pp[i][3]) << 16);
+                    *reinterpret_cast<uint2*>(q) = w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gc + e < cols) { p[o + e] = pp[i][e]; m[o + e] = mm[i][e]; v[o + e] = vv[i][e]; q[e] = m2f_bf16_bits(pp[i][e]); }
+                }
+            }
+        }
+        __syncthreads();
+        {   // W^T shadow: 8 consecutive source rows of one column per lane = 16 bytes of a dst_t row (m2f_tile64)
+            const int r8 = tid & 7;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cc = (tid >> 3) + 32 * j;
+                const int gcol = c0 + cc, gr0 = r0 + 8 * r8;
+                if (gcol < cols && gr0 < ldt) {
+                    uint16_t h[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) h[k] = m2f_bf16_bits(tile[8 * r8 + k][cc]);
+                    uint4 w;
+                    w.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); w.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                    w.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16); w.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+                    *reinterpret_cast<uint4*>(sh + it.soff_t + (long long)gcol * ldt + gr0) = w;      // soff_t, ldt: multiples of 8
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool BWD>
 hipError_t ln_launch(LnBatch& lb, hipStream_t stream) {
     if (lb.count <= 0 || lb.count > M2F_LN_MAX_PROBLEMS || lb.T <= 0) return hipErrorInvalidValue;
@@ -753,6 +875,17 @@ hipError_t m2f_launch_gather(const GatherArgs& a, hipStream_t stream) {
 
 hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream) {
     hipLaunchKernelGGL(m2f_rng_advance_kernel, dim3(1), dim3(64), 0, stream, rng);
+    return hipGetLastError();
+}
+
+hipError_t m2f_launch_adam_shadowed(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items,
+                                    const int* tile_begin, int n_items, int total_tiles, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, int step, const float* grad_scale_ptr, hipStream_t stream) {
+    if (n_items < 1 || n_items > M2F_ADAM_MAX_ITEMS || total_tiles < 1 || !items || !tile_begin || !shadow) return hipErrorInvalidValue;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int blocks = total_tiles < 256 * 8 ? total_tiles : 256 * 8;
+    hipLaunchKernelGGL(m2f_adam_shadow_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, shadow, items, tile_begin, n_items,
+                       total_tiles, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
     return hipGetLastError();
 }
 

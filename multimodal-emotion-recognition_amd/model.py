@@ -174,6 +174,27 @@ class _Engine:
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
         self.stream = torch.cuda.Stream(device=device)    # hipGraph capture is illegal on the default stream
         self.precision = runtime.PRECISIONS[model.precision]
+        # bf16 mode: ONE buffer of bf16 parameter shadows (W and W^T of every 2-D parameter) for all plans, kept current by
+        # FusedAdam.step itself (m2f_adam_step_shadowed).  `_fresh_token` = the parameters' version counters at the moment the
+        # optimizer last wrote the shadows: any later in-place change through torch (load_state_dict, a foreign optimizer,
+        # p.mul_()) moves the counters, the plans then re-cast the shadows at the head of their forward as before.  Writes that
+        # bypass the counters (p.data..., flat_parameters()[...] = ...) need `invalidate_shadows()`.  M2F_SHARED_SHADOWS=0: off.
+        self.wshadow: Optional[torch.Tensor] = None
+        self._fresh_token = None
+        if self.precision == runtime.BF16 and os.environ.get("M2F_SHARED_SHADOWS", "1") != "0":
+            self.wshadow = runtime.param_shadow_buffer(self.cfg, device)
+
+    def _version_token(self):
+        return sum(p._version for (p, _, _, _) in self.items)
+
+    def mark_shadows_fresh(self) -> None:
+        self._fresh_token = self._version_token()
+
+    def invalidate_shadows(self) -> None:
+        self._fresh_token = None
+
+    def shadows_fresh(self) -> bool:
+        return self.wshadow is not None and self._fresh_token is not None and self._fresh_token == self._version_token()
 
     def ensure_grad(self) -> torch.Tensor:
         if self.flat_grad is None:
@@ -229,12 +250,15 @@ class _Engine:
             if train:
                 self.ensure_grad()
             self._evict(max(self.max_plans, 1) - 1, self.max_plan_bytes)
-            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng, T=T)
+            pl = runtime.Plan(cfg, B, L, self.precision, train, self.flat, self.flat_grad_ext if train else None, self.rng, T=T,
+                              param_shadow=self.wshadow)
+            pl._on_cast = self.mark_shadows_fresh
             self.plans[key] = pl
             self._evict(max(self.max_plans, 1), self.max_plan_bytes, protect=key)
         else:
             self.plans.move_to_end(key)
             self._evict(max(self.max_plans, 1), self.max_plan_bytes, protect=key)      # (the caps may have been lowered since)
+        pl.params_fresh(self.shadows_fresh())
         return pl
 
     def _room_for(self, nbytes: int) -> bool:
@@ -391,6 +415,12 @@ class M2FNet(nn.Module):
             loss = body()
         eng.publish_grads()
         return loss[0].clone()          # (the buffer is overwritten by the next step)
+
+    def invalidate_shadows(self) -> None:
+        """Call after writing parameters in a way torch's version counters do not see (``p.data`` edits, writes through
+        ``flat_parameters()``): the next forward re-casts the bf16 parameter shadows."""
+        if self._engine is not None:
+            self._engine.invalidate_shadows()
 
     def flat_parameters(self) -> torch.Tensor:
         return self.engine().flat

@@ -107,8 +107,15 @@ class FusedAdam(torch.optim.Optimizer):
                 elif p.grad.data_ptr() != view.data_ptr():
                     view.copy_(p.grad)
         self._step += 1
-        runtime.adam_step(eng.flat, flat_grad, self._m, self._v, self._step, g["lr"], g["betas"], g["eps"],
-                          g["weight_decay"], self.grad_scale)
+        if eng.wshadow is not None:
+            # bf16 mode: the update and the bf16 shadows (W, W^T) of every 2-D parameter in ONE pass - the forward then skips its
+            # parameter casts (engine.shadows_fresh)
+            runtime.adam_step_shadowed(eng.cfg, eng.flat, flat_grad, self._m, self._v, eng.wshadow, self._step, g["lr"], g["betas"],
+                                       g["eps"], g["weight_decay"], self.grad_scale)
+            eng.mark_shadows_fresh()
+        else:
+            runtime.adam_step(eng.flat, flat_grad, self._m, self._v, self._step, g["lr"], g["betas"], g["eps"],
+                              g["weight_decay"], self.grad_scale)
         return loss
 
     @torch.no_grad()
@@ -123,6 +130,7 @@ class FusedAdam(torch.optim.Optimizer):
         flat_grad = eng.ensure_grad() if grads is None else grads
         n = eng.flat.numel()
         self._step += 1
+        eng.invalidate_shadows()              # this path updates the parameters only: the next forward re-casts their bf16 shadows
         for i, (lo, hi) in enumerate(ranges):
             if before_each is not None:
                 before_each(i)

@@ -61,6 +61,14 @@ SIGNATURES = {
                                    c_void_p, c_int64, c_void_p]),
     "m2f_plan_create_packed": (c_void_p, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                           c_void_p, c_int64, c_void_p]),
+    "m2f_param_shadow_elems": (c_int64, [ctypes.POINTER(M2FConfigC)]),
+    "m2f_param_shadow_init": (c_int, [ctypes.POINTER(M2FConfigC), c_void_p, c_void_p]),
+    "m2f_workspace_bytes_shared": (c_int64, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int]),
+    "m2f_plan_create_shared": (c_void_p, [ctypes.POINTER(M2FConfigC), c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_void_p, c_void_p]),
+    "m2f_plan_params_fresh": (c_int, [c_void_p, c_int]),
+    "m2f_adam_step_shadowed": (c_int, [ctypes.POINTER(M2FConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                       c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "m2f_plan_destroy": (None, [c_void_p]),
     "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
     "m2f_plan_num_launches": (c_int, [c_void_p, c_int]),
@@ -180,16 +188,24 @@ class Plan:
     """One bound launch list (config, B, L, precision, train/eval) + its workspace."""
 
     def __init__(self, cfg: M2FConfig, B: int, L: int, precision: int, train: bool, params: torch.Tensor,
-                 grads: Optional[torch.Tensor], rng_state: Optional[torch.Tensor], T: Optional[int] = None):
+                 grads: Optional[torch.Tensor], rng_state: Optional[torch.Tensor], T: Optional[int] = None,
+                 param_shadow: Optional[torch.Tensor] = None):
         """T: PACKED plan (m2f_plan_create_packed) - T token rows shared by the B dialogues through cu_seqlens; `set_inputs`
-        packs the padded batch it is given and `logits` unpacks, so callers see the padded [B, L, ...] surface either way."""
+        packs the padded batch it is given and `logits` unpacks, so callers see the padded [B, L, ...] surface either way.
+        param_shadow: the model's shared bf16 parameter-shadow buffer (m2f_plan_create_shared); None = the plan keeps its own."""
         require_gpu()
         self.packed = T is not None
         self.cfg, self.B, self.L, self.T = cfg, B, L, (int(T) if self.packed else B * L)
         self.precision, self.train = precision, train
         self._cc = config_to_c(cfg)
-        nbytes = (lib().m2f_workspace_bytes_packed(ctypes.byref(self._cc), B, L, self.T, int(train)) if self.packed
-                  else lib().m2f_workspace_bytes(ctypes.byref(self._cc), B, L, int(train)))
+        self.shared_shadow = param_shadow is not None
+        self._fresh = False
+        self._on_cast = None      # engine hook: a forward that re-cast the shared parameter shadows leaves them current
+        if self.shared_shadow:
+            nbytes = lib().m2f_workspace_bytes_shared(ctypes.byref(self._cc), B, L, self.T if self.packed else 0, int(train))
+        else:
+            nbytes = (lib().m2f_workspace_bytes_packed(ctypes.byref(self._cc), B, L, self.T, int(train)) if self.packed
+                      else lib().m2f_workspace_bytes(ctypes.byref(self._cc), B, L, int(train)))
         if nbytes < 0:
             raise HipError(lib().m2f_last_error().decode())
         self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=params.device)
@@ -198,8 +214,12 @@ class Plan:
         torch.cuda.current_stream(params.device).synchronize()
         base = self.workspace.data_ptr()
         self._ws_off = (-base) % 256
-        self._keep = (params, grads, rng_state)
-        if self.packed:
+        self._keep = (params, grads, rng_state, param_shadow)
+        if self.shared_shadow:
+            self.handle = lib().m2f_plan_create_shared(ctypes.byref(self._cc), B, L, self.T if self.packed else 0, precision,
+                                                       int(train), params.data_ptr(), ptr(grads), base + self._ws_off, nbytes,
+                                                       ptr(rng_state), param_shadow.data_ptr())
+        elif self.packed:
             self.handle = lib().m2f_plan_create_packed(ctypes.byref(self._cc), B, L, self.T, precision, int(train),
                                                        params.data_ptr(), ptr(grads), base + self._ws_off, nbytes, ptr(rng_state))
         else:
@@ -284,6 +304,13 @@ class Plan:
 
     def num_launches(self) -> Dict[str, int]:
         return {k: lib().m2f_plan_num_launches(self._h(), i) for i, k in enumerate(("forward", "loss", "backward"))}
+
+    def params_fresh(self, fresh: bool) -> None:
+        """Declare the shared parameter shadows current (the optimizer wrote them) or stale (the forward re-casts them)."""
+        fresh = bool(fresh) and self.shared_shadow
+        if fresh != self._fresh:
+            check(lib().m2f_plan_params_fresh(self._h(), int(fresh)), "m2f_plan_params_fresh")
+            self._fresh = fresh
 
     def hold(self, node) -> None:
         """A forward ran under autograd: `node` (its grad_fn) will call backward() on these activations."""
@@ -379,9 +406,14 @@ class Plan:
             self._dlogits.zero_()                 # filler slots of a bucketed plan carry no gradient
         self._dlogits[: self.in_B, : self.in_L].copy_(g.reshape(self.in_B, self.in_L, -1))
 
+    def _casted(self) -> None:
+        if self.shared_shadow and not self._fresh and self._on_cast is not None:
+            self._on_cast()
+
     def forward(self) -> torch.Tensor:
         self.version += 1
         check(lib().m2f_forward(self._h(), stream_ptr()), "m2f_forward")
+        self._casted()
         return self.logits
 
     def nbytes(self) -> int:
@@ -400,6 +432,7 @@ class Plan:
         self.version += 1
         check(lib().m2f_step(self._h(), label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
                              stream_ptr()), "m2f_step")
+        self._casted()
         return self.loss
 
     def step_timed(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True):
@@ -411,6 +444,7 @@ class Plan:
                                  n_max, kinds, ms, fl)
         if n < 0:
             raise HipError("m2f_step_timed: " + lib().m2f_last_error().decode())
+        self._casted()
         return [(kinds[i], ms[i], fl[i]) for i in range(n)]
 
     def close(self) -> None:
@@ -431,6 +465,30 @@ def event_overhead(pairs: int = 200):
     a, b = c_float(0), c_float(0)
     check(lib().m2f_event_overhead(scratch.data_ptr(), pairs, ctypes.byref(a), ctypes.byref(b), stream_ptr()), "m2f_event_overhead")
     return a.value, b.value
+
+
+def param_shadow_buffer(cfg: M2FConfig, device) -> torch.Tensor:
+    """The shared bf16 parameter-shadow buffer of a model (+ the fused optimizer's tensor table behind it), initialised."""
+    cc = config_to_c(cfg)
+    n = lib().m2f_param_shadow_elems(ctypes.byref(cc))
+    if n < 0:
+        raise HipError(lib().m2f_last_error().decode())
+    buf = torch.empty(n + 128, dtype=torch.int16, device=device)
+    off = ((-buf.data_ptr()) % 256) // 2
+    buf = buf[off: off + n]
+    torch.cuda.current_stream(buf.device).synchronize()
+    check(lib().m2f_param_shadow_init(ctypes.byref(cc), buf.data_ptr(), stream_ptr()), "m2f_param_shadow_init")
+    return buf
+
+
+def adam_step_shadowed(cfg: M2FConfig, params, grads, exp_avg, exp_avg_sq, param_shadow, step: int, lr: float,
+                       betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                       grad_scale: Optional[torch.Tensor] = None) -> None:
+    """torch.optim.Adam's update over the whole flat buffers + the bf16 shadows of every 2-D parameter (m2f_adam_step_shadowed)."""
+    cc = config_to_c(cfg)
+    check(lib().m2f_adam_step_shadowed(ctypes.byref(cc), params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(),
+                                       exp_avg_sq.data_ptr(), param_shadow.data_ptr(), lr, betas[0], betas[1], eps,
+                                       weight_decay, step, ptr(grad_scale), stream_ptr()), "m2f_adam_step_shadowed")
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,

@@ -18,6 +18,7 @@
 // (cheap at these sizes) so dQ and dK/dV need no transposes and no atomics.
 #include "common.h"
 #include "ops.h"
+#include <cstdlib>
 
 // No floating-point contraction in this file: the launch-list kernels and the persistent kernel (mega.hip) restate the same
 // formulas in different surroundings, and with -ffp-contract=fast (the HIP default) the compiler is free to fuse a*b+c in one
@@ -272,8 +273,9 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     float* Ks = Qs + Lp * ld;
     float* Vs = Ks + Lp * ld;
     float* Gs = Vs + Lp * ld;          // dO
-    float* Os = Gs + Lp * ld;          // O (one-round-trip path only: present when ab.bwd_fast)
-    float* delta = Os + (ab.bwd_fast ? Lp * ld : 0);       // [Lp]
+    float* Os = Gs + Lp * ld;          // O (only when ab.bwd_fast == 1: the one-round-trip path that keeps an O slab)
+    float* delta = Os + (ab.bwd_fast == 1 ? Lp * ld : 0);  // [Lp]
+    float* dpart = delta + Lp;         // [NV][NTHR] (ab.bwd_fast == 2: per-thread pieces of delta, summed per row in a fixed order)
     int L = LM;                                            // (packed layout: see the forward kernel)
     size_t tok0 = (size_t)b * LM;
     if (ab.cu) { const int c0 = ab.cu[b]; L = ab.cu[b + 1] - c0; tok0 = (size_t)c0; }
@@ -305,7 +307,18 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
             py = *reinterpret_cast<const f32x4*>(probs + (size_t)l15 * Lp + 4 * lg);
         }
         slab_commit(rg, G, Gs);
-        slab_commit(ro, G, Os);
+        if (ab.bwd_fast == 1) slab_commit(ro, G, Os);
+        else {
+            // delta_i = sum_c dO[i][c] O[i][c] straight from the registers both operands arrived in: no O slab, so four
+            // workgroups fit a CU's LDS (4 x 8.3 KB slabs at head dim 128) and the 1,024 (dialogue, head) problems of a merged
+            // encoder launch at C3 run in ONE round instead of 768 + 256.  Thread t's u-th float4 is element 4 (t + NTHR u) of
+            // the row-major [Lp][W] slab; row r sums its W / 4 pieces in index order (deterministic).
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const f32x4 a = rg.x[u], b = ro.x[u];
+                dpart[u * NTHR + tid] = G.ok[u] ? (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]) : 0.f;
+            }
+        }
         slab_commit(rv, G, Vs);
         slab_commit(rk, G, Ks);
         slab_commit(rq, G, Qs);
@@ -323,6 +336,14 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     __syncthreads();
     // delta_i = sum_c dO[i][c] * O[i][c]  (= sum_j P[i][j] dP[i][j], also under dropout).  Four lanes per row, each
     // takes a quarter of the row (O from its LDS slab, or streamed from global memory on the slow path), shuffle-reduce.
+    if (fast && ab.bwd_fast == 2) {
+        if (tid < Lp) {
+            const int C4 = W >> 2;
+            float d = 0.f;
+            for (int e = tid * C4; e < (tid + 1) * C4; ++e) d += dpart[e];     // e = t + NTHR u  ->  dpart[u * NTHR + t] = dpart[e]
+            delta[tid] = tid < L ? d : 0.f;
+        }
+    } else
     for (int r0 = 0; r0 < Lp; r0 += NTHR / 4) {
         const int row = r0 + (tid >> 2), part = tid & 3;
         const bool rin = row < Lp, rok = row < L;
@@ -627,8 +648,12 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
         if (W > maxW) maxW = W;
     }
     // one-round-trip backward: every problem's slabs fit the register form (NV = 2 * Lp/16 float4) and the fifth (O) slab fits LDS
-    ab.bwd_fast = BWD && maxW <= 128 && ((size_t)5 * Lp * (maxW + 2) + Lp) * sizeof(float) <= 160 * 1024;
-    const size_t lds = (size_t)(BWD ? (ab.bwd_fast ? 5 : 4) : 3) * Lp * (maxW + 2) * sizeof(float) + (BWD ? Lp * sizeof(float) : 0);
+    // (2 = the default: O never enters LDS, see the kernel; 1 = with an O slab, the form the parked persistent kernels repeat -
+    // M2F_ATTN_BWD_OSLAB=1 selects it so that their bit-for-bit tests still compare like with like)
+    static const bool oslab = getenv("M2F_ATTN_BWD_OSLAB") && getenv("M2F_ATTN_BWD_OSLAB")[0] == '1';
+    ab.bwd_fast = (BWD && maxW <= 128 && ((size_t)5 * Lp * (maxW + 2) + Lp) * sizeof(float) <= 160 * 1024) ? (oslab ? 1 : 2) : 0;
+    const size_t lds = (size_t)(BWD ? (ab.bwd_fast == 1 ? 5 : 4) : 3) * Lp * (maxW + 2) * sizeof(float) +
+                       (BWD ? (Lp + (ab.bwd_fast == 2 ? 2 * NT * NTHR : 0)) * sizeof(float) : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define M2F_ATTN_CASE(N)                                                                                   \
     case N: {                                                                                              \

@@ -19,6 +19,16 @@
 #include "ops.h"
 #include "mega.h"
 
+// The persistent strip-dataflow kernels (mega.hip) are PARKED (round 3): correct and bit-identical to the launch lists, but
+// slower (C3 fwd+bwd 3.34 vs 2.70 ms, profiles/r02_bench_c3_bf16_persistent_kernels.json), so the default library is built
+// without them.  `make -C csrc mega` builds libm2fnet_hip_mega.so with them (-DM2F_WITH_MEGA); M2F_LIB=<that> M2F_MEGA=1 runs them.
+#ifndef M2F_WITH_MEGA
+hipError_t m2f_launch_mega(const MegaArgs&, int, int, hipStream_t) { return hipErrorNotSupported; }      // (never reached: no plan turns them on)
+#define M2F_MEGA_AVAILABLE 0
+#else
+#define M2F_MEGA_AVAILABLE 1
+#endif
+
 #ifndef M2F_TABLE_TILE_DEFAULT
 #define M2F_TABLE_TILE_DEFAULT 131      // weight-gradient table launch: see build_plan (M2F_TABLE_TILE)
 #endif
@@ -996,7 +1006,7 @@ void build_mega(m2f_plan& P, Arena& ar, bool real) {
     uint32_t* status = ar.alloc<uint32_t>(16);
     P.mega_status = status;
     unsigned long long* prof = ar.alloc<unsigned long long>(2 * 64);     // diagnostic builds (-DM2F_MEGA_PROF) only
-    const bool use = real && want && fits && P.prec == M2F_PREC_BF16;
+    const bool use = M2F_MEGA_AVAILABLE && real && want && fits && P.prec == M2F_PREC_BF16;
     {
         MegaTables mt;
         mega_tables(P, P.fwd, 0, halves_fwd, halves_bwd, mt);

@@ -448,10 +448,15 @@ class Plan:
         return [(kinds[i], ms[i], fl[i]) for i in range(n)]
 
     def close(self) -> None:
-        """Destroy the plan (captured graph, launch lists) and drop its workspace."""
+        """Destroy the plan (captured graph, launch lists) and drop its workspace.  A plan that ran the (parked) persistent
+        kernels reports a bounded wait that ran out here at the latest - such a launch ends with wrong results, not a hang."""
         h = getattr(self, "handle", None)
         if h and _lib is not None:
-            _lib.m2f_plan_destroy(h)
+            try:
+                if _lib.m2f_plan_persistent(h):
+                    self.check_status()
+            finally:
+                _lib.m2f_plan_destroy(h)
         self.handle = None
         self.workspace = None
 

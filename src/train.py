@@ -241,6 +241,10 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
                 loss.backward()
             optimizer.step()
         running += loss.item()
+        if step == 0 and hasattr(model, "engine"):         # (parked persistent kernels only: a give-up must not pass as a loss)
+            for plan in model.engine().plans.values():
+                if plan.persistent():
+                    plan.check_status()
         if wandb_log:
             wandb.log({"Train/Running_loss": running / (step + 1), "Params/Global_step": epoch * len(dl_train) + step})
     return running / len(dl_train)

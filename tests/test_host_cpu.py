@@ -195,6 +195,36 @@ def test_spill_guard_of_the_gemm_build(tmp_path):
     assert remarks([(tn, 0)]).returncode != 0          # no kernel of the guarded form found: the remark format changed
 
 
+def test_spill_guard_of_the_ring_builds(tmp_path):
+    """check_spills.py --ring (run by the Makefile on every gemm_ring_*.hip): a ring-form kernel waits for its LDS-DMA loads
+    with hand-counted vmcnt, and scratch traffic shares that counter - any scratch use must fail the build (a 256x128
+    row-major table build with 112 bytes of scratch per lane existed for an hour in round 3)."""
+    import subprocess
+    script = os.path.join(ROOT, "multimodal-emotion-recognition_amd", "csrc", "check_spills.py")
+
+    def remarks(entries):
+        out = []
+        for name, scratch in entries:
+            out.append(f"./gemm_ring.h:650:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]")
+            out.append("./gemm_ring.h:650:1: remark:     VGPRs: 254 [-Rpass-analysis=kernel-resource-usage]")
+            out.append(f"./gemm_ring.h:650:1: remark:     ScratchSize [bytes/lane]: {scratch} [-Rpass-analysis=kernel-resource-usage]")
+        p = tmp_path / "ring.txt"
+        p.write_text("\n".join(out) + "\n")
+        return subprocess.run([sys.executable, script, "--ring", str(p)], capture_output=True, text=True)
+
+    a = "_ZN12_GLOBAL__N_122m2f_gemm16_ring_kernelILi256ELi128ELi3ELb1ELb1ELi1EEEv9GemmBatch"
+    b = "_ZN12_GLOBAL__N_122m2f_gemm16_ring_kernelILi128ELi128ELi4ELb1ELb1ELi1EEEv9GemmBatch"
+    assert remarks([(a, 0), (b, 0)]).returncode == 0
+    bad = remarks([(a, 112), (b, 0)])
+    assert bad.returncode == 1 and "112 bytes of scratch" in bad.stderr
+    assert remarks([("some_other_kernel", 0)]).returncode != 0
+    for name in ("gemm_ring_128x128", "gemm_ring_128x64", "gemm_ring_64x64", "gemm_ring_256x128", "gemm_ring_table"):
+        built = os.path.join(ROOT, "multimodal-emotion-recognition_amd", "csrc", name + ".remarks")
+        if os.path.exists(built):                   # written by the build: the shipped kernels must be clean
+            r = subprocess.run([sys.executable, script, "--ring", built], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+
+
 def test_asm_load_checker_flags_a_copy_of_a_register_in_flight():
     """csrc/check_asm_loads.py (run by the Makefile on gemm.hip's ISA): a register that an inline-asm load is still filling
     must not be read, copied or overwritten before the hand-written wait - the pattern that corrupted a build in round 2."""

@@ -45,3 +45,18 @@ def test_product_module_has_transformers_state_dict_keys():
     import pytest
     with pytest.raises(runtime.HipError):
         m(torch.zeros(1, 4, dtype=torch.int64))                      # no GPU here: fails loudly, no CPU fallback
+
+
+def test_text_context_construction_matches_reference(golden_dir):
+    """f4 / BASELINE C5: `prev </s> utterance </s> next` of src/feature_extractors/text/utils.py:61-92 - fixture written by the
+    reference's own function (tests/golden/make_golden_context.py); the row-by-row restatement and the one-pass builder both
+    reproduce every string (first / last / only utterance of a dialogue, gaps in the ids, rows out of order)."""
+    import json
+    import os
+    from mer_amd import text_context as tc
+    with open(os.path.join(golden_dir, "text_contexts.json"), encoding="utf-8") as f:
+        fx = json.load(f)
+    u, d, i, sep = fx["utterances"], fx["dialogue_ids"], fx["utterance_ids"], fx["separator"]
+    assert len(u) >= 10 and any(c.startswith(sep + " ") for c in fx["contexts"]) and any(c.endswith(" " + sep) for c in fx["contexts"])
+    assert [tc.utterance_with_context(u, d, i, k, sep) for k in range(len(u))] == fx["contexts"]
+    assert tc.build_contexts(u, d, i, sep) == fx["contexts"]

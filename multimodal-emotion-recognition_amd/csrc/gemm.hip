@@ -1389,8 +1389,8 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
     return t;
 }
 
-int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin) {
-    constexpr int TILE = 128;                                   // tile_n
+int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, int tile_n, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin) {
+    const int TILE = tile_n;
     tile_rec.clear();
     wg_begin.assign((size_t)n_wg + 1, 0);
     if (n_wg < 1 || prs.size() > 65535) return -1;
@@ -1474,7 +1474,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile == 129 || gb.table_tile == 130 || gb.table_tile == 131) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
+    if (gb.table_tile >= 129 && gb.table_tile <= 132) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

@@ -122,14 +122,14 @@ hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream);
 #ifdef __cplusplus
 #include <vector>
 int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob, bool operand_options = false);
-// Per-workgroup tile lists of the ring table forms (tile_m x 128 tiles, tile_m = 128 or 256) for a grid of n_wg workgroups (workgroup b runs on XCD
+// Per-workgroup tile lists of the ring table forms (tile_m x tile_n tiles: 128x128, 256x128, 256x256) for a grid of n_wg workgroups (workgroup b runs on XCD
 // b % 8 under round-robin placement - speed only).  walk = 0: the order of m2f_gemm_table_layout (every round spreads 256
 // consecutive tiles - usually of ONE problem - over all eight XCDs, so each L2 pulls its own copy of that problem's
 // operands); walk = 1: the tile list is cut into eight contiguous ranges of whole 8 x 4 super-tiles, one per XCD, so a
 // problem's operand panels are fetched by one L2 (two at a range boundary) and the 32 tiles an XCD multiplies at a time
 // share 8 row panels and 4 column panels.  Returns the number of records (= total tiles), -1 if a problem has more than
 // 255 tiles along a dimension.
-int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin);
+int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, int tile_n, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin);
 #endif
 
 // ------------------------------------------------------------------------------------------------

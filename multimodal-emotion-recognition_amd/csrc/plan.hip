@@ -1128,8 +1128,8 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // tiles, 19.5 M with 256x128; 361 -> 290 us, profiles/r03_*).
     const char* tt_env = getenv("M2F_TABLE_TILE");
     const int tt = tt_env ? atoi(tt_env) : 0;
-    const int table_tile = (tt == 64 || tt == 128 || tt == 129 || tt == 130 || tt == 131 || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
-    const bool table_rc = table_tile == 130 || table_tile == 131;          // 131: 256 x 128 tiles
+    const int table_tile = (tt == 64 || tt == 128 || (tt >= 129 && tt <= 132) || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
+    const bool table_rc = table_tile >= 130 && table_tile <= 132;          // 131: 256 x 128 tiles, 132: 256 x 256 (gemm_rc256.hip)
     if (table_ok && table_rc) {
         // operands = shadows of the fp32 activations (same element index); every one of them is also the A operand of a
         // forward-form chain launch, so its shadow is current when the backward chain has run
@@ -1151,7 +1151,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
             if (b_ok && g.M <= 8 && !(g.flags & GF_RELU_A) && wg_cast.count < M2F_CAST_MAX_ITEMS) {
                 // a narrow dY without a 16-byte-stageable shadow (the [T, n_classes] criterion gradient): a bf16 copy with
                 // 8-column rows, made by a cast launch in front of the table launch (the pad column is zeroed once, here)
-                uint16_t* pad = bld.ar.alloc<uint16_t>((size_t)T * 8 + 256);      // + one 512-byte fragment row (256 x 128 tiles) past the end
+                uint16_t* pad = bld.ar.alloc<uint16_t>((size_t)T * 8 + 256);      // + one 512-byte fragment row (256-row tiles) past the end
                 if (ws_base && hipMemset(pad, 0, ((size_t)T * 8 + 256) * sizeof(uint16_t)) != hipSuccess) { table_ok = false; break; }
                 CastItem& ci = wg_cast.it[wg_cast.count++];
                 ci.src = g.a.p[0]; ci.dst = pad; ci.rows = T; ci.cols = g.M; ci.lds = g.a.ld[0]; ci.ldd = 8; ci.dst_t = nullptr; ci.ldd_t = 0;
@@ -1212,18 +1212,21 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // Tile choice, measured: 256x128 register-staged tiles beat 128x128 ones on the transposed copies (a quarter fewer operand
     // bytes through L1: 145 vs 183 us at C2) and also the ring form on the same copies (129: C3 step 3.707 vs 3.655 ms - this
     // launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together, so bytes per FLOP decide).
-    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : (table_tile == 131 ? 256 : table_tile), tile_prob, table_rc);
+    const int walk_m = (table_tile == 131 || table_tile == 132) ? 256 : 128, walk_n = table_tile == 132 ? 256 : 128;
+    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : (table_tile == 131 || table_tile == 132 ? 256 : table_tile), tile_prob, table_rc);
     if (total_tiles <= 0) table_ok = false;
     // ring table forms: per-workgroup tile lists (m2f_gemm_table_walk).  M2F_TABLE_WALK=0 (read when a plan is built) keeps the
     // order of the tile list; default 1 = every XCD walks its own problems in 8 x 4 super-tiles
     std::vector<uint32_t> tile_rec;
     std::vector<int> wg_begin;
-    const bool table_ring = table_tile == 129 || table_tile == 130 || table_tile == 131;
+    const bool table_ring = table_tile >= 129 && table_tile <= 132;
     int wg_count = 0;
     if (table_ok && table_ring) {
         const char* walk_env = getenv("M2F_TABLE_WALK");
+        if (m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, 256, walk_m, walk_n, tile_rec, wg_begin) <= 0) table_ok = false;
+        total_tiles = (int)tile_rec.size();                     // (the tile count of THIS tiling; tile_prob above serves the register-staged forms only)
         wg_count = std::min(total_tiles, 256);
-        if (m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, wg_count, table_tile == 131 ? 256 : 128, tile_rec, wg_begin) != total_tiles) table_ok = false;
+        if (table_ok && wg_count < 256 && m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, wg_count, walk_m, walk_n, tile_rec, wg_begin) <= 0) table_ok = false;
     }
     GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;
     uint16_t* d_tile_prob = table_ok ? bld.ar.alloc<uint16_t>(tile_prob.size()) : nullptr;

@@ -89,7 +89,7 @@ __device__ __forceinline__ bool slab_fast_ok(const float* src, int ldg, int hd, 
     return ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (Lp * (W >> 2) <= NTHR * NV);
 }
 template <int NV>
-struct SlabRegs { f32x4 x[NV]; };
+struct SlabRegs { f32x4 x[NV]; uint32_t w0[NV], w1[NV]; };     // w0 / w1: the raw 4 bf16 of a chunk staged from a shadow
 template <int NV>
 __device__ __forceinline__ void slab_issue(SlabRegs<NV>& R, const SlabGeom<NV>& G, const float* __restrict__ src, int ldg) {
 #pragma unroll
@@ -99,22 +99,74 @@ __device__ __forceinline__ void slab_issue(SlabRegs<NV>& R, const SlabGeom<NV>& 
         R.x[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src) + (size_t)o);
     }
 }
+// bf16 mode: the same slab from the operand's bf16 SHADOW (same element index; the producer wrote both copies): half the bytes
+// of the kernels' dominant cost - at C3 a merged encoder launch of the backward kernel read 37 MB of fp32 slabs.  The raw
+// 8 bytes (4 bf16) wait in w0 / w1 until slab_value() widens them (exact: bf16 -> fp32 is a shift).
 template <int NV>
-__device__ __forceinline__ void slab_commit(const SlabRegs<NV>& R, const SlabGeom<NV>& G, float* __restrict__ lds) {
+__device__ __forceinline__ void slab_issue16(SlabRegs<NV>& R, const SlabGeom<NV>& G, const uint16_t* __restrict__ src, int ldg) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int r = G.goff_rc[u] >> 16, c = G.goff_rc[u] & 0xFFFF;
+        const uint32_t o = G.ok[u] ? (uint32_t)(r * ldg + c) * 2u : 0u;
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(src) + (size_t)o);
+        R.w0[u] = w.x; R.w1[u] = w.y;
+    }
+}
+template <int NV>
+__device__ __forceinline__ f32x4 slab_value(const SlabRegs<NV>& R, int u, bool from16) {
+    if (!from16) return R.x[u];
+    const uint32_t a = R.w0[u], b = R.w1[u];
+    const f32x4 v = {__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xFFFF0000u),
+                     __builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xFFFF0000u)};
+    return v;
+}
+// the bf16 shadow of `p` if this launch may stage from it (bf16 mode, shadowed buffer, 8-byte aligned rows), else null
+__device__ __forceinline__ const uint16_t* slab_shadow(const AttnBatch& ab, const float* p, int ldg, int hd, int bit) {
+    if (!(ab.bf16_math & bit)) return nullptr;
+    const uint16_t* q = m2f_shadow_of(ab.sh, p);
+    return (q && ((reinterpret_cast<uintptr_t>(q) & 7) == 0) && ((ldg & 3) == 0) && ((hd & 3) == 0)) ? q : nullptr;
+}
+
+template <int NV>
+__device__ __forceinline__ void slab_commit(const SlabRegs<NV>& R, const SlabGeom<NV>& G, float* __restrict__ lds, bool from16 = false) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         if (G.inb[u]) {
             const bool ok = G.ok[u];
+            const f32x4 v = slab_value(R, u, from16);
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2* d = reinterpret_cast<f32x2*>(lds + G.loff[u]);          // r*(W+2) + c is even: 8-byte aligned
-            d[0] = f32x2{ok ? R.x[u][0] : 0.f, ok ? R.x[u][1] : 0.f};
-            d[1] = f32x2{ok ? R.x[u][2] : 0.f, ok ? R.x[u][3] : 0.f};
+            d[0] = f32x2{ok ? v[0] : 0.f, ok ? v[1] : 0.f};
+            d[1] = f32x2{ok ? v[2] : 0.f, ok ? v[3] : 0.f};
         }
     }
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// bf16 mode: C[m][n] = sum_k A[m][k] B[n][k] over the W (padded head dim) columns of two fp32 LDS slab rows per lane, operands
+// rounded to bf16 on the way into v_mfma_f32_16x16x32_bf16 (lane l15 = its row of A and of B, lane >> 4 = which 8 of the 32 k).
+// Same C layout as the chain of mfma4's it replaces: 4 MFMAs of 16 cycles for head dim 128 instead of 32 of 32 cycles - with four
+// workgroups per CU the exact-fp32 contractions were ~5 us of the backward kernel's 19.
+__device__ __forceinline__ bf16x8 slab8_bf16(const float* p, bool in) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2* q = reinterpret_cast<const f32x2*>(p);                  // 8-byte aligned: slab strides and k offsets are even
+    const f32x2 z = {0.f, 0.f};
+    const f32x2 a = in ? q[0] : z, b = in ? q[1] : z, c = in ? q[2] : z, d = in ? q[3] : z;
+    const bf16x8 r = {(__bf16)a[0], (__bf16)a[1], (__bf16)b[0], (__bf16)b[1], (__bf16)c[0], (__bf16)c[1], (__bf16)d[0], (__bf16)d[1]};
+    return r;
+}
+__device__ __forceinline__ f32x4 dot_rows_bf16(const float* arow, const float* brow, int W, int lg) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < W; k0 += 32) {
+        const int k = k0 + 8 * lg;
+        const bool in = k < W;                                           // W is a multiple of 16: the last step may be half a step
+        const int kc = in ? k : 0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(slab8_bf16(arow + kc, in), slab8_bf16(brow + kc, in), acc, 0, 0, 0);
+    }
+    return acc;
 }
 
 template <int NT>
@@ -147,12 +199,15 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
         SlabGeom<NV> G;
         slab_geom(G, L, hd, Lp, W, ld, tid);
         SlabRegs<NV> rq, rk, rv;                              // one round trip for the three operands
-        slab_issue(rq, G, qg, P.ldq);
-        slab_issue(rk, G, kg, P.ldk);
-        slab_issue(rv, G, vg, P.ldv);
-        slab_commit(rq, G, Qs);
-        slab_commit(rk, G, Ks);
-        slab_commit(rv, G, Vs);
+        const uint16_t* q16 = slab_shadow(ab, qg, P.ldq, hd, 2);
+        const uint16_t* k16 = slab_shadow(ab, kg, P.ldk, hd, 4);
+        const uint16_t* v16 = slab_shadow(ab, vg, P.ldv, hd, 8);
+        if (q16) slab_issue16(rq, G, q16, P.ldq); else slab_issue(rq, G, qg, P.ldq);
+        if (k16) slab_issue16(rk, G, k16, P.ldk); else slab_issue(rk, G, kg, P.ldk);
+        if (v16) slab_issue16(rv, G, v16, P.ldv); else slab_issue(rv, G, vg, P.ldv);
+        slab_commit(rq, G, Qs, q16 != nullptr);
+        slab_commit(rk, G, Ks, k16 != nullptr);
+        slab_commit(rv, G, Vs, v16 != nullptr);
     } else {
         load_slab(Qs, ld, Lp, W, qg, P.ldq, L, hd, tid);
         load_slab(Ks, ld, Lp, W, kg, P.ldk, L, hd, tid);
@@ -176,6 +231,10 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
         const int i = 16 * it + l15;                        // this lane's query row
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
+            if (ab.bf16_math & 1) {
+                s[jt] = dot_rows_bf16(Ks + (16 * jt + l15) * ld, Qs + i * ld, W, lg);
+                continue;
+            }
             // two interleaved accumulators: the 16x16x4 MFMA has a 40-cycle dependent latency at an 8..32-cycle issue
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* kp = Ks + (16 * jt + l15) * ld + lg;
@@ -296,18 +355,23 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
         SlabGeom<NV> G;
         slab_geom(G, L, hd, Lp, W, ld, tid);
         SlabRegs<NV> rq, rk, rv, rg, ro;                      // one round trip for all five operands (+ the probabilities)
-        slab_issue(rg, G, gg, P.lddo);
-        slab_issue(ro, G, og, P.ldo);
-        slab_issue(rv, G, vg, P.ldv);
-        slab_issue(rk, G, kg, P.ldk);
-        slab_issue(rq, G, qg, P.ldq);
+        const uint16_t* g16 = slab_shadow(ab, gg, P.lddo, hd, 16);
+        const uint16_t* o16 = slab_shadow(ab, og, P.ldo, hd, 32);
+        const uint16_t* v16 = slab_shadow(ab, vg, P.ldv, hd, 8);
+        const uint16_t* k16 = slab_shadow(ab, kg, P.ldk, hd, 4);
+        const uint16_t* q16 = slab_shadow(ab, qg, P.ldq, hd, 2);
+        if (g16) slab_issue16(rg, G, g16, P.lddo); else slab_issue(rg, G, gg, P.lddo);
+        if (o16) slab_issue16(ro, G, o16, P.ldo); else slab_issue(ro, G, og, P.ldo);
+        if (v16) slab_issue16(rv, G, v16, P.ldv); else slab_issue(rv, G, vg, P.ldv);
+        if (k16) slab_issue16(rk, G, k16, P.ldk); else slab_issue(rk, G, kg, P.ldk);
+        if (q16) slab_issue16(rq, G, q16, P.ldq); else slab_issue(rq, G, qg, P.ldq);
         if constexpr (NT == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) px[r] = probs[(size_t)(4 * lg + r) * Lp + l15];
             py = *reinterpret_cast<const f32x4*>(probs + (size_t)l15 * Lp + 4 * lg);
         }
-        slab_commit(rg, G, Gs);
-        if (ab.bwd_fast == 1) slab_commit(ro, G, Os);
+        slab_commit(rg, G, Gs, g16 != nullptr);
+        if (ab.bwd_fast == 1) slab_commit(ro, G, Os, o16 != nullptr);
         else {
             // delta_i = sum_c dO[i][c] O[i][c] straight from the registers both operands arrived in: no O slab, so four
             // workgroups fit a CU's LDS (4 x 8.3 KB slabs at head dim 128) and the 1,024 (dialogue, head) problems of a merged
@@ -315,13 +379,13 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
             // the row-major [Lp][W] slab; row r sums its W / 4 pieces in index order (deterministic).
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                const f32x4 a = rg.x[u], b = ro.x[u];
+                const f32x4 a = slab_value(rg, u, g16 != nullptr), b = slab_value(ro, u, o16 != nullptr);
                 dpart[u * NTHR + tid] = G.ok[u] ? (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]) : 0.f;
             }
         }
-        slab_commit(rv, G, Vs);
-        slab_commit(rk, G, Ks);
-        slab_commit(rq, G, Qs);
+        slab_commit(rv, G, Vs, v16 != nullptr);
+        slab_commit(rk, G, Ks, k16 != nullptr);
+        slab_commit(rq, G, Qs, q16 != nullptr);
     } else {
         load_slab(Qs, ld, Lp, W, qg, P.ldq, L, hd, tid);
         load_slab(Ks, ld, Lp, W, kg, P.ldk, L, hd, tid);
@@ -376,6 +440,9 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (ab.bf16_math & 1) {
+                acc0 = dot_rows_bf16(Vs + (16 * jt + l15) * ld, Gs + i * ld, W, lg);
+            } else {
             const float* vp = Vs + (16 * jt + l15) * ld + lg;
             const float* gp = Gs + i * ld + lg;
             int ks = 0;
@@ -384,6 +451,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 acc1 = mfma4(vp[4 * ks + 4], gp[4 * ks + 4], acc1);
             }
             if (ks < ksteps) acc0 = mfma4(vp[4 * ks], gp[4 * ks], acc0);
+            }
             const f32x4 acc = acc0 + acc1;                  // dP[i][j]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -423,6 +491,9 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (ab.bf16_math & 1) {
+                acc0 = dot_rows_bf16(Gs + (16 * it + l15) * ld, Vs + j * ld, W, lg);
+            } else {
             const float* gp = Gs + (16 * it + l15) * ld + lg;
             const float* vp = Vs + j * ld + lg;
             int ks = 0;
@@ -431,6 +502,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 acc1 = mfma4(gp[4 * ks + 4], vp[4 * ks + 4], acc1);
             }
             if (ks < ksteps) acc0 = mfma4(gp[4 * ks], vp[4 * ks], acc0);
+            }
             const f32x4 acc = acc0 + acc1;                  // dP[i][j]
             const f32x4 p4 = (NT == 1) ? py : *reinterpret_cast<const f32x4*>(probs + (size_t)j * Lp + 16 * it + 4 * lg);
 #pragma unroll

@@ -1474,7 +1474,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile >= 129 && gb.table_tile <= 132) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
+    if (gb.table_tile >= 129 && gb.table_tile <= 131) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

@@ -162,6 +162,9 @@ struct AttnBatch {
     float drop_scale;
     ShadowMap sh;              // out (fwd) / dq, dk, dv (bwd) also written as bf16
     int bwd_fast;              // set by the launcher: LDS holds the fifth (O) slab of the one-round-trip backward path
+    int bf16_math;             // bf16 mode, bit mask: 1 = the head-dim contractions (Q K^T, dO V^T) round their operands to bf16 and run
+                               // on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): 1/8 of the MFMA instructions at 1/2 the cycles each;
+                               // 2 / 4 / 8 / 16 / 32 = the Q / K / V / dO / O slab is staged from the operand's bf16 shadow (half the bytes)
 };
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
 // Long-sequence forward (S unbounded, hd <= 128): token-level self-attention of the in-loop text encoder (inference).

@@ -800,6 +800,10 @@ void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Laun
                 l.ab.B = P.B; l.ab.L = P.L; l.ab.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
                 l.ab.cu = P.packed ? P.cu : nullptr; l.ab.T = P.T;
                 l.ab.rng = P.rng; l.ab.drop_thresh = P.drop_thresh; l.ab.drop_scale = P.drop_scale;
+                {   // M2F_ATTN_BF16=<mask> (read when a plan is built; AttnBatch::bf16_math): 0 keeps the fp32 slabs / contractions in bf16 mode too
+                    const char* e = getenv("M2F_ATTN_BF16");
+                    l.ab.bf16_math = P.prec == M2F_PREC_BF16 ? (e ? atoi(e) & 63 : 63) : 0;
+                }
                 break;
             case OP_LN_FWD: case OP_LN_BWD:
                 l.lb.count = (int)o.lp.size();
@@ -1128,8 +1132,10 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // tiles, 19.5 M with 256x128; 361 -> 290 us, profiles/r03_*).
     const char* tt_env = getenv("M2F_TABLE_TILE");
     const int tt = tt_env ? atoi(tt_env) : 0;
-    const int table_tile = (tt == 64 || tt == 128 || (tt >= 129 && tt <= 132) || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
-    const bool table_rc = table_tile >= 130 && table_tile <= 132;          // 131: 256 x 128 tiles, 132: 256 x 256 (gemm_rc256.hip)
+    const int table_tile = (tt == 64 || tt == 128 || (tt >= 129 && tt <= 131) || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
+    const bool table_rc = table_tile == 130 || table_tile == 131;          // 131: 256 x 128 tiles
+    // (256 x 256 tiles - eight waves that all load and multiply, no producer waves: the accumulators fill the register file -
+    //  were built and measured SLOWER, 342 vs 296 us: commit c3f1730)
     if (table_ok && table_rc) {
         // operands = shadows of the fp32 activations (same element index); every one of them is also the A operand of a
         // forward-form chain launch, so its shadow is current when the backward chain has run
@@ -1212,14 +1218,14 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // Tile choice, measured: 256x128 register-staged tiles beat 128x128 ones on the transposed copies (a quarter fewer operand
     // bytes through L1: 145 vs 183 us at C2) and also the ring form on the same copies (129: C3 step 3.707 vs 3.655 ms - this
     // launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together, so bytes per FLOP decide).
-    const int walk_m = (table_tile == 131 || table_tile == 132) ? 256 : 128, walk_n = table_tile == 132 ? 256 : 128;
-    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : (table_tile == 131 || table_tile == 132 ? 256 : table_tile), tile_prob, table_rc);
+    const int walk_m = table_tile == 131 ? 256 : 128, walk_n = 128;
+    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : (table_tile == 131 ? 256 : table_tile), tile_prob, table_rc);
     if (total_tiles <= 0) table_ok = false;
     // ring table forms: per-workgroup tile lists (m2f_gemm_table_walk).  M2F_TABLE_WALK=0 (read when a plan is built) keeps the
     // order of the tile list; default 1 = every XCD walks its own problems in 8 x 4 super-tiles
     std::vector<uint32_t> tile_rec;
     std::vector<int> wg_begin;
-    const bool table_ring = table_tile >= 129 && table_tile <= 132;
+    const bool table_ring = table_tile >= 129 && table_tile <= 131;
     int wg_count = 0;
     if (table_ok && table_ring) {
         const char* walk_env = getenv("M2F_TABLE_WALK");
@@ -1548,6 +1554,13 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
 
 int m2f_plan_persistent(m2f_plan* plan) { return plan ? (plan->mfwd.on ? 1 : 0) | (plan->mbwd.on ? 2 : 0) : 0; }
 
+/* diagnostic (not part of the ABI header): where the activation shadows of a bf16 plan live */
+int m2f_dbg_shadow_map(m2f_plan* plan, const float** ws_base, uint16_t** shadow, int64_t* floats) {
+    if (!plan) return 1;
+    *ws_base = plan->sh.ws_base; *shadow = plan->sh.shadow; *floats = (int64_t)plan->sh.ws_floats;
+    return 0;
+}
+
 int m2f_plan_params_fresh(m2f_plan* plan, int fresh) {
     if (!plan) return fail("m2f_plan_params_fresh: NULL plan (destroyed?)");
     if (fresh && !plan->ext_wshadow) return fail("m2f_plan_params_fresh: only plans created with m2f_plan_create_shared can skip their parameter casts");
@@ -1875,6 +1888,11 @@ static void attn_fill(AttnBatch& ab, int B, int L, int H, int hd, const float* q
     p.H = H; p.hd = hd; p.drop_site = drop_site;
     ab.count = 1; ab.B = B; ab.L = L; ab.key_pad = key_pad; ab.rng = rng_state;
     ab.drop_scale = 1.f;
+    ab.sh = g_sh;                                              // (m2f_set_shadow_map: operands / results inside that range have bf16 copies)
+    {   // kernel-level tests of the bf16-mode forms: M2F_ATTN_BF16_KERNEL=<mask> (AttnBatch::bf16_math), read per call
+        const char* e = getenv("M2F_ATTN_BF16_KERNEL");
+        ab.bf16_math = e ? atoi(e) & 63 : 0;
+    }
     if (drop_site) drop_params(drop_p, &ab.drop_thresh, &ab.drop_scale);
 }
 

@@ -330,3 +330,54 @@ def test_adam_matches_torch():
         runtime.adam_step(p4, g16, m4, v4, step, 1e-3, (0.9, 0.999), 1e-8, 0.01, grad_scale=den)
         runtime.adam_step(p5, g16.float(), m5, v5, step, 1e-3, (0.9, 0.999), 1e-8, 0.01, grad_scale=den)
     assert torch.equal(p4, p5) and torch.equal(m4, m5) and torch.equal(v4, v5)
+
+
+@pytest.mark.parametrize("B,L,H,hd,ld", [(32, 16, 5, 60, 904), (16, 16, 8, 96, 2304), (4, 9, 8, 128, 3072), (3, 33, 4, 32, 392)])
+def test_attention_bf16_mode_forms(B, L, H, hd, ld, monkeypatch):
+    """bf16 mode runs the dialogue attention kernels in two cheaper forms (AttnBatch::bf16_math; M2F_ATTN_BF16_KERNEL selects them
+    for the kernel-level entry points): (a) the Q / K / V (backward: + dO, O) slabs are staged from the operands' bf16 shadows -
+    bit for bit what the fp32 kernel computes on inputs rounded to bf16; (b) the head-dim contractions Q K^T and dO V^T run on the
+    bf16 MFMA - within bf16 rounding of (a)."""
+    from mer_amd import runtime
+    torch.manual_seed(B + hd)
+    d, T = H * hd, B * L
+    ws = torch.randn(2 * T, ld, device=DEV) * 0.5                     # rows [0, T): packed q | k | v, rows [T, 2T): dO | O
+    sh = ws.to(torch.bfloat16).contiguous()
+    wr = sh.float()
+    kp = torch.zeros(B, L, dtype=torch.bool, device=DEV)
+    kp[1, max(L // 2, 1):] = True
+    valid = ~kp.reshape(-1)
+
+    def shadows(on):
+        runtime.check(runtime.lib().m2f_set_shadow_map(ws.data_ptr() if on else None, sh.data_ptr() if on else None, ws.numel() if on else 0), "m2f_set_shadow_map")
+
+    def run(src, mask, with_shadows):
+        q, k, v, do = src[:T, :d], src[:T, d:2 * d], src[:T, 2 * d:3 * d], src[T:, :d]
+        monkeypatch.setenv("M2F_ATTN_BF16_KERNEL", str(mask))
+        shadows(with_shadows)
+        try:
+            out, probs = F.attention_fwd(q, k, v, kp, B, L, H)
+            o_in = src[T:, d:2 * d]
+            o_in.copy_(out)                                           # O at a place that has a shadow ...
+            if with_shadows:
+                sh[T:, d:2 * d].copy_(out.to(torch.bfloat16))          # ... which the forward kernel would have written
+            dq, dk, dv = F.attention_bwd(q, k, v, kp, o_in, probs, do, B, L, H)
+        finally:
+            shadows(False)
+            monkeypatch.setenv("M2F_ATTN_BF16_KERNEL", "0")
+        return out, dq, dk, dv
+
+    exact = run(ws.clone(), 0, False)                                  # fp32 kernel, unrounded inputs
+    rounded_src = wr.clone()
+    want = run(rounded_src, 0, False)                                  # fp32 kernel on bf16-rounded inputs
+    got = run(ws, 62, True)                                            # staged from the shadows, exact contractions
+    # (O enters the backward rounded too: `want` fed the fp32 O of its own forward, so compare the forward bit for bit and the
+    #  gradients to the rounding of O)
+    assert torch.equal(got[0][valid], want[0][valid])
+    for a, b in zip(got[1:], want[1:]):
+        assert (a - b)[valid].abs().max().item() <= 2e-2 * b[valid].abs().max().item()
+    both = run(ws, 63, True)                                           # + bf16 contractions
+    for a, b, e in zip(both, got, exact):
+        scale = e[valid].abs().max().item()
+        assert (a - b)[valid].abs().max().item() <= 2e-2 * scale
+        assert (a - e)[valid].abs().max().item() <= 3e-2 * scale

@@ -125,6 +125,16 @@ int m2f_backward(m2f_plan* plan, m2f_stream_t stream);
 int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, int use_graph,
              m2f_stream_t stream);
 
+/* The same step in TWO parts, for data-parallel overlap (no counterpart in the reference, which is single-process):
+ *   part 0 = dropout-RNG advance + forward + criterion + the backward chain of the classifier and the fusion stack + every weight
+ *            gradient whose operands that chain completes;   part 1 = the encoders' backward + the remaining weight gradients.
+ * After part 0 the flat gradient buffer is final from element m2f_plan_split_offset(plan) on (fusion stack + classifier = its
+ * tail, and the 64-float loss tail behind it), so a rank can put that bucket's all-reduce on the wire and run part 1 under it.
+ * m2f_plan_split_offset returns 0 for plans that cannot be split (fp32 mode, eval plans); parts 0 and 1 must alternate. */
+int64_t m2f_plan_split_offset(m2f_plan* plan);
+int m2f_step_part(m2f_plan* plan, int part, float label_smoothing, int use_class_weights, int normalise, int use_graph,
+                  m2f_stream_t stream);
+
 /* Device-side dialogue batcher: Dataset.__getitem__ + collate_fn / apply_padding (src/dataset.py:32-89, src/utils.py:15-31)
  * on device-resident embedding tables.  Token slot t receives row rows[t] of each table; rows[t] < 0 marks a padded slot
  * (features 0, label -1, key_pad 1).  Outputs may be a plan's staging buffers (row strides ld_text / ld_audio). */

@@ -1389,12 +1389,20 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
     return t;
 }
 
-int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, int tile_n, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin) {
+int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs_all, int walk, int n_wg, int tile_m, int tile_n, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin,
+                        const std::vector<int>* only) {
     const int TILE = tile_n;
+    // `only` (nullable): walk just these problems (records still carry the index into prs_all = the device table)
+    std::vector<size_t> sel;
+    if (only) for (int i : *only) sel.push_back((size_t)i);
+    else for (size_t i = 0; i < prs_all.size(); ++i) sel.push_back(i);
+    struct View { const std::vector<GemmProblem>& a; const std::vector<size_t>& s; size_t size() const { return s.size(); }
+                  const GemmProblem& operator[](size_t i) const { return a[s[i]]; } } prs{prs_all, sel};
     tile_rec.clear();
     wg_begin.assign((size_t)n_wg + 1, 0);
-    if (n_wg < 1 || prs.size() > 65535) return -1;
-    auto rec = [](size_t p, int mt, int nt) { return (uint32_t)p | ((uint32_t)mt << 16) | ((uint32_t)nt << 24); };
+    if (n_wg < 1) return -1;
+    auto rec = [&](size_t p, int mt, int nt) { return (uint32_t)sel[p] | ((uint32_t)mt << 16) | ((uint32_t)nt << 24); };
+    if (prs_all.size() > 65535) return -1;
     std::vector<std::vector<uint32_t>> per_wg((size_t)n_wg);
     if (walk == 0) {
         // the order of m2f_gemm_table_layout (m fastest inside a problem), dealt as ring_xcd_remap deals it

@@ -129,7 +129,8 @@ int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<u
 // problem's operand panels are fetched by one L2 (two at a range boundary) and the 32 tiles an XCD multiplies at a time
 // share 8 row panels and 4 column panels.  Returns the number of records (= total tiles), -1 if a problem has more than
 // 255 tiles along a dimension.
-int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, int tile_n, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin);
+int m2f_gemm_table_walk(const std::vector<GemmProblem>& prs, int walk, int n_wg, int tile_m, int tile_n, std::vector<uint32_t>& tile_rec, std::vector<int>& wg_begin,
+                        const std::vector<int>* only = nullptr);
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -268,6 +268,17 @@ struct m2f_plan {
     TransBatch wg_trans = {nullptr, nullptr, 0, 0};
     GemmBatch wg_tab;
     double wg_flops = 0.0;
+    // SPLIT backward (m2f_step_part; data-parallel overlap): part 0 = forward + criterion + the classifier / fusion-stack backward
+    // chain (bwd[0, bwd_head)) + the weight gradients whose operands that chain completes; part 1 = the encoders' backward +
+    // the rest.  The fusion stack's and the classifier's gradients are the TAIL of the flat buffer (from split_offset on): their
+    // all-reduce can travel under part 1.  Same table, two tile lists.
+    size_t bwd_head = 0;
+    bool split_ok = false;
+    int64_t split_offset = 0;
+    GemmBatch wg_tab_part[2];
+    size_t wg_rest_head = 0;             // wg_rest[0, wg_rest_head) belong to part 0
+    hipGraphExec_t gexec_part[2] = {nullptr, nullptr};
+    float gp_ls[2] = {0.f, 0.f}; int gp_cw[2] = {-1, -1}, gp_norm[2] = {-1, -1}, gp_fresh[2] = {-1, -1};
     std::vector<LnReduceBatch> lnred;
     // strip-dataflow persistent kernels (mega.h, bf16 mode): the whole forward launch list, and the backward list from
     // `first` on, as ONE launch each.  M2F_MEGA=0 (read when a plan is built) keeps the launch lists.
@@ -281,6 +292,7 @@ struct m2f_plan {
     bool warmed = false;          // one eager step (sets kernel attributes) before the first capture
     ~m2f_plan() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
+        for (hipGraphExec_t g : gexec_part) if (g) (void)hipGraphExecDestroy(g);
     }
 };
 
@@ -1073,6 +1085,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
         for (int b = 0; b < 2; ++b)
             for (size_t i = 0; i < bld.br_b[b].size(); ++i) bld.br_b[b][i].src.push_back({b, (int)i});
         to_launches(P, bld.chain_b, P.bwd);
+        P.bwd_head = P.bwd.size();
         to_launches(P, merge_chains(bld.br_b[0], bld.br_b[1]), P.bwd);
         // where did (chain, index) end up in the final launch order?
         auto final_index = [&](std::pair<int, int> tag) {
@@ -1118,6 +1131,8 @@ int build_plan(m2f_plan& P, char* ws_base) {
     std::vector<TransItem> titems;
     std::vector<uint16_t> tblock;
     std::vector<GemmProblem> tprobs;
+    std::vector<int> tprob_head, tprob_rest;   // indices into tprobs by backward part (m2f_step_part)
+    size_t rest_head = 0;
     std::vector<uint16_t> tile_prob;
     // M2F_WGRAD_TABLE=0 (read when a plan is built) keeps the grouped row-contiguous launches in bf16 mode too: the parity
     // tests compare the two weight-gradient paths against each other
@@ -1148,7 +1163,9 @@ int build_plan(m2f_plan& P, char* ws_base) {
         std::vector<Op> rest_ops;
         CastBatch wg_cast;
         memset(&wg_cast, 0, sizeof(wg_cast));
-        for (const GemmProblem& g : bld.wgrads) {
+        for (size_t gi = 0; gi < bld.wgrads.size(); ++gi) {
+            const GemmProblem& g = bld.wgrads[gi];
+            const bool head = bld.wdeps[gi].first == 2;        // both operands exist once the classifier / fusion backward chain has run
             const uint16_t* qa = shadow_ptr(g.a.p[0]);
             const uint16_t* qb = shadow_ptr(g.b.p[0]);
             if (g.a.k[1] != 0 || g.b.k[1] != 0) { table_ok = false; break; }
@@ -1167,7 +1184,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
                 // no 16-byte-stageable shadow (the [T, n_classes] criterion gradient): a grouped launch of its own
                 Op o; o.kind = OP_GEMM; o.layout = M2F_LAYOUT_TN;
                 o.gp.push_back(g);
-                rest_ops.push_back(o);
+                if (head) { rest_ops.insert(rest_ops.begin() + (ptrdiff_t)rest_head, o); ++rest_head; } else rest_ops.push_back(o);
                 continue;
             }
             GemmProblem q;
@@ -1177,10 +1194,11 @@ int build_plan(m2f_plan& P, char* ws_base) {
             q.M = g.M; q.N = g.N; q.c = g.c; q.ldc = g.ldc; q.gate_scale = 1.f;
             q.flags = g.flags & (uint32_t)(GF_RELU_A | GF_RELU_B);
             q.bias_grad = g.bias_grad;
+            (head ? tprob_head : tprob_rest).push_back((int)tprobs.size());
             tprobs.push_back(q);
             P.wg_flops += 2.0 * g.M * g.N * (double)T;
         }
-        if (table_ok) to_launches(P, rest_ops, P.wg_rest);
+        if (table_ok) { to_launches(P, rest_ops, P.wg_rest); P.wg_rest_head = rest_head; }
         if (table_ok && wg_cast.count) P.wg_casts.push_back(wg_cast);
     }
     if (table_ok && !table_rc) {
@@ -1234,10 +1252,30 @@ int build_plan(m2f_plan& P, char* ws_base) {
         wg_count = std::min(total_tiles, 256);
         if (table_ok && wg_count < 256 && m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, wg_count, walk_m, walk_n, tile_rec, wg_begin) <= 0) table_ok = false;
     }
+    std::vector<uint32_t> part_rec[2];
+    std::vector<int> part_begin[2];
+    int part_wg[2] = {0, 0};
+    bool split = table_ok && table_ring && table_rc && P.bwd_head > 0 && P.bwd_head < P.bwd.size() && !tprob_head.empty() && !tprob_rest.empty();
+    if (split) {
+        const char* walk_env = getenv("M2F_TABLE_WALK");
+        for (int part = 0; part < 2 && split; ++part) {
+            const std::vector<int>& sub = part == 0 ? tprob_head : tprob_rest;
+            if (m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, 256, walk_m, walk_n, part_rec[part], part_begin[part], &sub) <= 0) split = false;
+            part_wg[part] = std::min((int)part_rec[part].size(), 256);
+            if (split && part_wg[part] < 256 &&
+                m2f_gemm_table_walk(tprobs, walk_env ? atoi(walk_env) : 1, part_wg[part], walk_m, walk_n, part_rec[part], part_begin[part], &sub) <= 0) split = false;
+        }
+    }
     GemmProblem* d_table = table_ok ? bld.ar.alloc<GemmProblem>(tprobs.size()) : nullptr;
     uint16_t* d_tile_prob = table_ok ? bld.ar.alloc<uint16_t>(tile_prob.size()) : nullptr;
     uint32_t* d_tile_rec = table_ok && table_ring ? bld.ar.alloc<uint32_t>(tile_rec.size()) : nullptr;
     int* d_wg_begin = table_ok && table_ring ? bld.ar.alloc<int>(wg_begin.size()) : nullptr;
+    uint32_t* d_part_rec[2] = {nullptr, nullptr};
+    int* d_part_begin[2] = {nullptr, nullptr};
+    for (int part = 0; part < 2; ++part) {                          // (same allocations in the sizing pass: `split` does not depend on pointers)
+        d_part_rec[part] = split ? bld.ar.alloc<uint32_t>(part_rec[part].size()) : nullptr;
+        d_part_begin[part] = split ? bld.ar.alloc<int>(part_begin[part].size()) : nullptr;
+    }
     TransItem* d_items = table_ok ? bld.ar.alloc<TransItem>(titems.size()) : nullptr;
     uint16_t* d_tblock = table_ok ? bld.ar.alloc<uint16_t>(tblock.size()) : nullptr;
     P.ws_used = bld.ar.off;
@@ -1252,6 +1290,10 @@ int build_plan(m2f_plan& P, char* ws_base) {
             ok = ok && hipMemcpy(d_items, titems.data(), titems.size() * sizeof(TransItem), hipMemcpyHostToDevice) == hipSuccess;
             ok = ok && hipMemcpy(d_tblock, tblock.data(), tblock.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
         }
+        for (int part = 0; part < 2 && split; ++part) {
+            ok = ok && hipMemcpy(d_part_rec[part], part_rec[part].data(), part_rec[part].size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+            ok = ok && hipMemcpy(d_part_begin[part], part_begin[part].data(), part_begin[part].size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+        }
         if (ok) {
             P.wg_nt = true;
             P.wg_trans = {d_items, d_tblock, (int)tblock.size(), T};
@@ -1259,6 +1301,14 @@ int build_plan(m2f_plan& P, char* ws_base) {
             P.wg_tab.table = d_table; P.wg_tab.tile_prob = d_tile_prob; P.wg_tab.total_tiles = total_tiles; P.wg_tab.table_tile = table_tile;
             P.wg_tab.tile_rec = d_tile_rec; P.wg_tab.wg_begin = d_wg_begin; P.wg_tab.wg_count = wg_count;
             P.wg_tab.rng = P.rng; P.wg_tab.drop_thresh = P.drop_thresh; P.wg_tab.drop_scale = P.drop_scale;
+            for (int part = 0; part < 2 && split; ++part) {
+                P.wg_tab_part[part] = P.wg_tab;
+                P.wg_tab_part[part].tile_rec = d_part_rec[part]; P.wg_tab_part[part].wg_begin = d_part_begin[part];
+                P.wg_tab_part[part].wg_count = part_wg[part]; P.wg_tab_part[part].total_tiles = (int)part_rec[part].size();
+            }
+            // the fusion stack's (else the classifier's) first parameter: everything from there on is complete after part 0
+            P.split_ok = split;
+            P.split_offset = (int64_t)(c.fam_enabled && !P.pm.fam.empty() ? P.pm.fam[0].in_w : P.pm.cls[0].w);
         }
     }
     if (P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
@@ -1266,6 +1316,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
         P.sh = {wsf, shadow, ws_floats};
         P.wshadow = wshadow;
         P.wg_tab.sh = P.sh;
+        P.wg_tab_part[0].sh = P.sh; P.wg_tab_part[1].sh = P.sh;
         auto map_q = [&](GemmOperand& o) {
             for (int sgm = 0; sgm < 2; ++sgm) {
                 o.q[sgm] = nullptr; o.ldq[sgm] = 0; o.qt[sgm] = nullptr; o.ldqt[sgm] = 0;
@@ -1397,6 +1448,22 @@ int run_mega(m2f_plan::MegaRun& run, int prof_kind, hipStream_t s) {
     if (g_prof) g_prof->begin(prof_kind, run.flops);
     M2F_HIP(m2f_launch_mega(run.args, run.nt, run.grid, s));
     if (g_prof) g_prof->end();
+    return 0;
+}
+
+// part 0 / 1 of the split backward (see m2f_plan::bwd_head)
+int do_backward_part(m2f_plan& P, int part, hipStream_t s) {
+    if (!P.split_ok) return fail("m2f_step_part: this plan has no split backward (bf16 train plans with the row-major weight-gradient table only)");
+    if (part == 0) {
+        if (int r = run_launches(P, P.bwd, s, 0, P.bwd_head)) return r;
+        for (const CastBatch& cb : P.wg_casts) M2F_HIP(m2f_launch_cast(cb, s));
+        M2F_HIP(m2f_launch_gemm_table(P.wg_tab_part[0], s));
+        return run_launches(P, P.wg_rest, s, 0, P.wg_rest_head);
+    }
+    if (int r = run_launches(P, P.bwd, s, P.bwd_head)) return r;
+    M2F_HIP(m2f_launch_gemm_table(P.wg_tab_part[1], s));
+    if (int r = run_launches(P, P.wg_rest, s, P.wg_rest_head)) return r;
+    for (const LnReduceBatch& rb : P.lnred) M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
     return 0;
 }
 
@@ -1731,6 +1798,50 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
         P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise; P.g_fresh = (int)P.params_fresh;
     }
     M2F_HIP(hipGraphLaunch(P.gexec, s));
+    return 0;
+}
+
+int64_t m2f_plan_split_offset(m2f_plan* plan) { return plan && plan->split_ok && !plan->mbwd.on && !plan->mfwd.on ? plan->split_offset : 0; }
+
+int m2f_step_part(m2f_plan* plan, int part, float label_smoothing, int use_class_weights, int normalise, int use_graph,
+                  m2f_stream_t stream) {
+    if (!plan) return fail("m2f_step_part: NULL plan (destroyed?)");
+    m2f_plan& P = *plan;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!P.train || part < 0 || part > 1) return fail("m2f_step_part needs a train plan and part 0 or 1");
+    if (!P.split_ok || P.mfwd.on || P.mbwd.on) return fail("m2f_step_part: this plan has no split backward");
+    auto body = [&]() -> int {
+        if (part == 0) {
+            if (P.use_dropout) M2F_HIP(m2f_launch_rng_advance(P.rng, s));
+            if (int r = do_forward(P, s)) return r;
+            if (int r = do_loss(P, label_smoothing, use_class_weights, normalise, s)) return r;
+        }
+        return do_backward_part(P, part, s);
+    };
+    if (!use_graph || !P.warmed) {
+        const int r = body();
+        if (part == 1) P.warmed = true;
+        return r;
+    }
+    hipGraphExec_t& ge = P.gexec_part[part];
+    if (ge && (P.gp_ls[part] != label_smoothing || P.gp_cw[part] != use_class_weights || P.gp_norm[part] != normalise ||
+               P.gp_fresh[part] != (int)P.params_fresh)) {
+        (void)hipGraphExecDestroy(ge);
+        ge = nullptr;
+    }
+    if (!ge) {
+        hipGraph_t graph = nullptr;
+        M2F_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int r = body();
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+        if (e != hipSuccess) return hipfail(e, "hipStreamEndCapture");
+        e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { ge = nullptr; return hipfail(e, "hipGraphInstantiate"); }
+        P.gp_ls[part] = label_smoothing; P.gp_cw[part] = use_class_weights; P.gp_norm[part] = normalise; P.gp_fresh[part] = (int)P.params_fresh;
+    }
+    M2F_HIP(hipGraphLaunch(ge, s));
     return 0;
 }
 

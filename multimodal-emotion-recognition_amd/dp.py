@@ -207,6 +207,46 @@ class GradReducer:
         work = [_all_reduce_sum(self.buf[a:b], self.group) for a, b in order]
         optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
 
+    def reduce_and_step_split(self, optimizer, run_rest, split: int) -> None:
+        """Exchange overlapped with the backward pass: the caller has run part 0 of the step (everything from element `split` of
+        the buffer on is final: the fusion stack's and the classifier's gradients + the loss tail), `run_rest()` enqueues part 1
+        (the encoders' backward).  The tail bucket's all-reduce is put on the wire FIRST - torch's asynchronous collectives wait for
+        the work already queued on the current stream, i.e. for part 0 only - then part 1 is enqueued and computes while that
+        bucket travels; the encoder buckets follow last-first as in `reduce_and_step`, each bucket's fused-Adam launch behind its
+        own collective.  At C3 the tail bucket is 35.5 M of 103.8 M parameters (71 MB of the 198 MB bf16 exchange)."""
+        if not dist.is_initialized():
+            run_rest()
+            optimizer.step()
+            return
+        split = max(0, min(int(split) // 64 * 64, self.n))
+        n_b = max(1, len(self.chunks) - 1)
+        edges = [round(i * split / n_b / 64) * 64 for i in range(n_b)] + [split]
+        head = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]            # encoder part of the parameters, in buckets
+        if self.exchange == "bf16":
+            tail = self.buf[self.n:]
+            work_tail = _all_reduce_sum(tail, self.group)                       # (loss, den, num): fp32
+            self.buf16[split:self.n].copy_(self.buf[split:self.n])
+            work_first = _all_reduce_sum(self.buf16[split:self.n], self.group) if self.n > split else None
+            run_rest()
+            order = [(split, self.n)] + list(reversed(head))
+            work = [work_first]
+            for a, b in order[1:]:
+                self.buf16[a:b].copy_(self.buf[a:b])
+                work.append(_all_reduce_sum(self.buf16[a:b], self.group))
+
+            def wait(i):
+                if i == 0:
+                    work_tail.wait()
+                if work[i] is not None:
+                    work[i].wait()
+            optimizer.step_ranges(order, before_each=wait, grads=self.buf16)
+            return
+        work_first = _all_reduce_sum(self.buf[split:], self.group)               # fusion stack + classifier + (loss, den, num)
+        run_rest()
+        order = [(split, self.buf.numel())] + list(reversed(head))
+        work = [work_first] + [_all_reduce_sum(self.buf[a:b], self.group) for a, b in order[1:]]
+        optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
+
     @property
     def global_den(self) -> torch.Tensor:          # device scalar view, feeds m2f_adam_step(grad_scale_ptr)
         return self.buf[self.n + 1: self.n + 2]
@@ -249,8 +289,11 @@ class DataParallelStep:
     """One optimizer step of dialogue-sharded data-parallel training:
     m2f_step(normalise=0) -> tail <- (den, num) -> all-reduce -> fused Adam with grad_scale = global den."""
 
-    def __init__(self, model, optimizer, group=None, n_buckets: int = 4, exchange: str = "fp32"):
-        self.model, self.optimizer = model, optimizer
+    def __init__(self, model, optimizer, group=None, n_buckets: int = 4, exchange: str = "fp32", overlap: bool = True):
+        """overlap: with more than one rank, run the step in two parts (runtime.Plan.step_part) and put the all-reduce of the
+        fusion stack's / classifier's gradients on the wire before the encoders' backward starts (plans that cannot be split -
+        fp32 mode - exchange after the whole backward as before)."""
+        self.model, self.optimizer, self.overlap = model, optimizer, overlap
         eng = model.engine()
         eng.ensure_grad()
         self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets, exchange)
@@ -276,9 +319,16 @@ class DataParallelStep:
                             mask, emotion)
             if class_weights is not None:
                 plan.class_w[: class_weights.numel()].copy_(class_weights)
-            plan.step(label_smoothing, class_weights is not None, False, use_graph)   # tail <- (loss, den, num)
-            eng.publish_grads()
-            self.reducer.reduce_and_step(self.optimizer)
+            split = plan.split_offset() if (self.overlap and self.reducer.world() > 1) else 0
+            if split > 0:
+                cw = class_weights is not None
+                plan.step_part(0, label_smoothing, cw, False, use_graph)              # tail <- (loss, den, num); fusion / classifier gradients final
+                eng.publish_grads()
+                self.reducer.reduce_and_step_split(self.optimizer, lambda: plan.step_part(1, label_smoothing, cw, False, use_graph), split)
+            else:
+                plan.step(label_smoothing, class_weights is not None, False, use_graph)   # tail <- (loss, den, num)
+                eng.publish_grads()
+                self.reducer.reduce_and_step(self.optimizer)
             loss = self.reducer.global_loss()
         cur.wait_stream(eng.stream)
         return loss

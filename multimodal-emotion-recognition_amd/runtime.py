@@ -79,6 +79,8 @@ SIGNATURES = {
     "m2f_loss": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),
     "m2f_backward": (c_int, [c_void_p, c_void_p]),
     "m2f_step": (c_int, [c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "m2f_plan_split_offset": (c_int64, [c_void_p]),
+    "m2f_step_part": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]),
     "m2f_step_timed": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_int),
                                ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double)]),
     "m2f_event_overhead": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
@@ -433,6 +435,21 @@ class Plan:
         check(lib().m2f_step(self._h(), label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
                              stream_ptr()), "m2f_step")
         self._casted()
+        return self.loss
+
+    def split_offset(self) -> int:
+        """First element of the flat gradient buffer that is final after `step_part(0)` (0: this plan cannot be split)."""
+        return int(lib().m2f_plan_split_offset(self._h()))
+
+    def step_part(self, part: int, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True,
+                  use_graph: bool = True) -> torch.Tensor:
+        """m2f_step_part: part 0 = forward + criterion + classifier / fusion backward (+ their weight gradients), part 1 = the rest."""
+        if part == 0:
+            self.version += 1
+        check(lib().m2f_step_part(self._h(), int(part), label_smoothing, int(use_class_weights), int(normalise), int(use_graph),
+                                  stream_ptr()), "m2f_step_part")
+        if part == 0:
+            self._casted()
         return self.loss
 
     def step_timed(self, label_smoothing: float = 0.1, use_class_weights: bool = False, normalise: bool = True):

@@ -121,6 +121,21 @@ def main():
     res["B_rng"] = md.engine().rng.cpu().clone()
     res["B_grads"] = md.flat_gradients().detach().cpu().clone()
 
+    # ---- D: bf16 mode, exchange overlapped with the encoders' backward (step in two parts) vs exchange after the whole backward --
+    res["D"] = {}
+    for overlap in (True, False):
+        for exchange in ("fp32", "bf16"):
+            torch.manual_seed(0)
+            mb = M2FNet(cfg, precision="bf16").to(device).train()
+            mb.load_state_dict({k: v.to(device) for k, v in synth.make_state_dict(cfg).items()})
+            ob = FusedAdam(mb, lr=1e-3, weight_decay=0.01)
+            sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange=exchange, overlap=overlap)
+            losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(4)]
+            torch.cuda.synchronize()
+            plan = next(iter(mb.engine().plans.values()))
+            res["D"][(overlap, exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(),
+                                             "split": plan.split_offset(), "exchange": sb.reducer.exchange}
+
     # ---- C: the training loop of src/train.py under two ranks -----------------------------------------------------
     cfg_loop = loop_config(os.path.join(out_dir, "loop_dp"))
     res["C"] = run_training_loop(cfg_loop, device, world, rank)

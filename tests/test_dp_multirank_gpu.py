@@ -78,3 +78,18 @@ def test_training_loop_under_two_ranks_equals_the_single_process_loop(dp2_result
     ck_dp = torch.load(os.path.join(out_dir, "loop_dp", "ck", "m2fnet.pth"), weights_only=False)
     ck_1 = torch.load(cfg.checkpoint.save_path, weights_only=False)
     assert ck_dp["epoch"] == ck_1["epoch"] and list(ck_dp["model_state_dict"]) == list(ck_1["model_state_dict"])
+
+
+def test_overlapped_exchange_equals_exchange_after_backward(dp2_results):
+    """bf16 mode under two ranks: DataParallelStep runs the step in two parts (m2f_step_part) and sends the fusion stack's and the
+    classifier's gradients while the encoders' backward still runs.  Same sums, bucketed differently: losses and parameters after
+    four steps (eager, capture, replays) are bit for bit those of the exchange after the whole backward, on both ranks, for the
+    fp32 and the bf16 exchange."""
+    (r0, r1), _ = dp2_results
+    for exchange in ("fp32", "bf16"):
+        a, b = r0["D"][(True, exchange)], r0["D"][(False, exchange)]
+        assert a["split"] > 0 and b["split"] > 0                       # the plan can be split; `overlap=False` just does not use it
+        assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+        assert torch.equal(a["params"], b["params"])
+        assert torch.equal(a["params"], r1["D"][(True, exchange)]["params"])
+        assert a["losses"][-1] < a["losses"][0]

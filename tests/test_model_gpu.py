@@ -408,3 +408,47 @@ def test_device_dialogue_batcher_equals_collate():
     loss_b = m.train_step(ref["text"].cuda(), ref["audio"].cuda(), ref["padding_mask"].cuda(), ref["emotion"].cuda(),
                           use_graph=False).item()
     assert loss_a == loss_b
+
+
+@pytest.mark.parametrize("name,use_graph", [("tiny_ragged", False), ("c2_slice", True), ("tiny_shared_norm", True), ("tiny_no_fam", False)])
+def test_step_in_two_parts_equals_the_whole_step(golden_dir, name, use_graph):
+    """m2f_step_part (data-parallel overlap): part 0 + part 1 = m2f_step bit for bit (loss, logits, every gradient; eager and as two
+    captured graphs), and after part 0 ALONE the gradient buffer is already final from m2f_plan_split_offset on - the fusion
+    stack's and the classifier's parameters, i.e. the bucket that travels while part 1 runs."""
+    from mer_amd import layout
+    fx = _load(golden_dir, name)
+    cfg, text, audio, key_pad, emotion = _inputs(name, fx)
+    cfg = dict(cfg, dropout=0.3)
+    batch = [t.cuda() for t in (text, audio, key_pad, emotion)]
+
+    def fresh():
+        torch.manual_seed(3)
+        return _model(cfg, precision="bf16", train=True)
+
+    ref = fresh()
+    for _ in range(3 if use_graph else 1):
+        ref.train_step(*batch, use_graph=use_graph)
+    torch.cuda.synchronize()
+    ref_plan = next(iter(ref.engine().plans.values()))
+    ref_grad, ref_logits, ref_loss = ref.engine().flat_grad.clone(), ref_plan.logits.clone(), ref_plan.loss.clone()
+
+    m = fresh()
+    eng = m.engine()
+    plan = eng.plan(batch[2].shape[0], batch[2].shape[1], True, True)
+    split = plan.split_offset()
+    specs, _ = layout.param_specs(m.m2f_config)
+    first_tail = next(s for s in specs if s.name.startswith("fusion_layers.0.") or (not m.m2f_config.fam_enabled and s.name.startswith("output_layer.0.")))
+    assert split == first_tail.offset > 0
+    plan.set_inputs(*batch)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for it in range(3 if use_graph else 1):
+            plan.step_part(0, 0.1, False, True, use_graph)
+            if it == (2 if use_graph else 0):
+                side.synchronize()
+                after0 = eng.flat_grad.clone()
+            plan.step_part(1, 0.1, False, True, use_graph)
+    side.synchronize()
+    assert torch.equal(after0[split:], ref_grad[split:]), "the tail of the gradient buffer must be final after part 0"
+    assert torch.equal(eng.flat_grad, ref_grad)
+    assert torch.equal(plan.logits, ref_logits) and torch.equal(plan.loss[:3], ref_loss[:3])

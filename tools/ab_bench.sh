@@ -9,7 +9,7 @@ for r in $(seq 1 $rounds); do
   for v in "$@"; do
     name=${v%%|*}; rest=${v#*|}; envs=${rest%%|*}; args=${rest#*|}
     out=$R/gpurun_out/ab/${name}_r$r
-    env $envs python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --secondary none --dump-launches $out.launches $args > $out.json 2> $out.err || { echo "$name r$r FAILED"; tail -5 $out.err; continue; }
+    env $envs python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-parity-leg --repeats 1 --secondary none --dump-launches $out.launches $args > $out.json 2> $out.err || { echo "$name r$r FAILED"; tail -5 $out.err; continue; }
     python3 - "$name" "$r" "$out" <<'PY'
 import json, sys
 name, r, out = sys.argv[1:4]

@@ -14,7 +14,7 @@ P4="TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_REQ"
 i=0
 for P in "$P3" "$P4"; do
   i=$((i+1)); rm -rf /tmp/pl$i
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pl$i -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --secondary none "$@" > /dev/null 2>/tmp/pl$i.err || { echo "pass $i failed"; tail -3 /tmp/pl$i.err; }
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pl$i -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --secondary none --no-parity-leg --repeats 1 "$@" > /dev/null 2>/tmp/pl$i.err || { echo "pass $i failed"; tail -3 /tmp/pl$i.err; }
 done
 python3 - "$pat" <<'PY'
 import csv, glob, collections, sys

@@ -151,7 +151,7 @@ PARTS = ["encoders", "fusion", "classifier"]
 
 
 def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump="", packed=False,
-                 repeats=1):
+                 repeats=1, overlap=True):
     cfg, B, L = wl["cfg"], wl["B"], wl["L"]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=dtype, shape_buckets=False).to(device).train()      # the plan IS the workload's (B, L): no bucket padding
@@ -163,6 +163,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
     # --packed: token rows = valid utterances only (m2f_plan_create_packed); pays off with --ragged
     plan = eng.plan(B, L, True, True, n_valid if packed else None)
 
+    split = plan.split_offset() if (world > 1 and overlap) else 0
     side = torch.cuda.Stream(device=device)
     with torch.cuda.stream(side):
         # inputs are resident in the plan's staging buffers before the timed region starts
@@ -172,6 +173,13 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
             # bf16 mode, N = 1: the fused Adam kernel also writes the bf16 parameter shadows, the forward then skips its parameter
             # casts (the engine compares the parameters' version counters: any other write to them brings the casts back)
             plan.params_fresh(eng.shadows_fresh())
+            if split:
+                # N > 1: the step in two parts - the fusion stack's / classifier's gradient bucket (the tail of the flat buffer, final
+                # after part 0) is on the wire while the encoders' backward (part 1) runs; the encoder buckets follow, each bucket's
+                # fused-Adam launch behind its own collective
+                plan.step_part(0, 0.1, False, False, use_graph)
+                stepper.reducer.reduce_and_step_split(opt, lambda: plan.step_part(1, 0.1, False, False, use_graph), split)
+                return
             plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
             stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
 
@@ -273,7 +281,8 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         "config": {"workload": wl["name"] + (" [MELD-like ragged lengths, valid utterances counted]" if ragged else ""),
                    "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B, "valid_utterances": n_valid_all,
                    "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
-                   "step": "fwd+CE+bwd (1 hipGraph)" + (f" + RCCL grad all-reduce ({stepper.reducer.exchange})" if world > 1 else "") + " + fused Adam",
+                   "step": ("fwd+CE+bwd (1 hipGraph)" if not split else "fwd+CE+bwd in two hipGraphs") +
+                           (f" + {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} grad all-reduce ({stepper.reducer.exchange}" + (", fusion / classifier bucket sent under the encoders' backward)" if split else ")") if world > 1 else "") + " + fused Adam",
                    "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                    "launches_per_step": plan.num_launches(), "persistent_kernels": plan.persistent(),
                    "token_rows": plan.T, "plan_shape": [plan.B, plan.L], "packed": bool(plan.packed),
@@ -339,6 +348,8 @@ def main():
                     help="form the process group (gloo when there is no GPU), check its size against --gpus, print it, exit: "
                          "the launch path without the measurement (tests/test_dp_cpu.py)")
     ap.add_argument("--repeats", type=int, default=5, help="timed brackets of `--steps` steps each (the first one is `value`)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange all gradients after the whole backward (default: the fusion "
+                    "stack's / classifier's bucket travels under the encoders' backward)")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 parity mode) leg of the same workload")
     ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
                     help="second single-GPU configuration reported under `secondary` (N = 1 only)")
@@ -365,6 +376,9 @@ def main():
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev and os.environ.get("M2F_DIST_BACKEND") == "gloo" and n_dev > 0:
+        local = local % n_dev          # rehearsal only: several gloo ranks sharing one GPU (tests the N > 1 code path, not its speed)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     runtime.require_gpu()
@@ -373,7 +387,8 @@ def main():
     use_graph = not args.no_graph
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
-                       roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed, repeats=max(1, args.repeats))
+                       roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed, repeats=max(1, args.repeats),
+                       overlap=not args.no_overlap)
     if rank == 0:
         out = res
         if world == 1 and args.dtype == "bf16" and not args.no_parity_leg and not args.ragged and not args.packed:

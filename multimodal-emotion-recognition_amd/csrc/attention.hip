@@ -171,6 +171,7 @@ __device__ __forceinline__ f32x4 dot_rows_bf16(const float* arow, const float* b
 
 template <int NT>
 __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) {
+    m2f_kernarg_warm<0, 8, 192>();                  // the descriptor block (648 B + hidden arguments) in one miss
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int pi = 0;
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
 
 template <int NT>
 __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) {
+    m2f_kernarg_warm<0, 8, 192>();                  // the descriptor block (648 B + hidden arguments) in one miss
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int pi = 0;

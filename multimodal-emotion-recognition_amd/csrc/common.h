@@ -4,6 +4,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Kernel-argument warm-up.  The kernels take their launch descriptors (GemmBatch, AttnBatch, LnBatch: 0.5-3 KB) BY VALUE; the
+// kernarg segment of a launch is cold in the scalar cache and in L2, and hipcc issues its s_loads lazily - a grouped GEMM
+// prologue walked four DEPENDENT misses (hidden grid size -> total_tiles -> tb[] -> hot[pi]) before its first operand load.
+// One wave-wide batch of s_load_dword, one per 64-byte line the kernel is going to read, turns them into one miss + hits.
+// (The wait sits INSIDE the asm: the compiler does not track loads issued by inline asm, and the scratch register is dead
+// the moment the block ends.)
+#define M2F_KW1(op, i) "s_load_dword %0, %1, " op "+(" #i ")*64\n"
+#define M2F_KW8(op, b) M2F_KW1(op, b+0) M2F_KW1(op, b+1) M2F_KW1(op, b+2) M2F_KW1(op, b+3) M2F_KW1(op, b+4) M2F_KW1(op, b+5) M2F_KW1(op, b+6) M2F_KW1(op, b+7)
+// LINES (8, 16 or 24) consecutive 64-byte lines from byte offset B on, plus eight more from B2 on (B2 < 0: none; the hidden
+// arguments behind a large struct); every load writes the same scratch register.
+template <int B, int LINES = 8, int B2 = -1>
+__device__ __forceinline__ void m2f_kernarg_warm() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(M2F_NO_KERNARG_WARM)       // (the switch exists for A/B builds)
+    static_assert(B % 4 == 0 && (B2 < 0 || B2 % 4 == 0) && (LINES == 8 || LINES == 16 || LINES == 24), "dword offsets, whole groups of eight lines");
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int C = B2 < 0 ? B : B2;          // (no second range: its loads repeat the first lines - hits)
+    uint32_t t;
+    if constexpr (LINES == 8) asm volatile(M2F_KW8("%2", 0) M2F_KW8("%3", 0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(kp), "n"(B), "n"(C) : "memory");
+    else if constexpr (LINES == 16) asm volatile(M2F_KW8("%2", 0) M2F_KW8("%2", 8) M2F_KW8("%3", 0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(kp), "n"(B), "n"(C) : "memory");
+    else asm volatile(M2F_KW8("%2", 0) M2F_KW8("%2", 8) M2F_KW8("%2", 16) M2F_KW8("%3", 0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(kp), "n"(B), "n"(C) : "memory");
+#endif
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -678,6 +678,10 @@ template <int BM, int BN, int S, bool TABLE, bool RC = false, int EPI = (TABLE ?
 __global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
+    // everything both roles read before the first operand load - tb[], hot[] (bytes 0..735), count .. the hidden launch
+    // geometry (2900..3100) - and, for grouped launches, pr[0] / pr[1] (736..1280), which the epilogue reads
+    if constexpr (TABLE) m2f_kernarg_warm<0, 8, 2880 - 256>();
+    else m2f_kernarg_warm<0, 24, 2880 - 256>();
     // grouped launches: workgroup b walks tiles remap(b), + grid, ... of the launch's tile list; TABLE form: its own list
     // (gb.tile_rec[gb.wg_begin[b] .. gb.wg_begin[b + 1]), built by m2f_gemm_table_walk)
     const int grid = TABLE ? 1 : (int)gridDim.x;

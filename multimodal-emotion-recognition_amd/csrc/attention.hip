@@ -225,6 +225,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
     if (site) key = m2f_site_key(ab.rng, site);
     float* probs = P.probs + (size_t)bh * Lp * Lp;
     uint16_t* out16 = m2f_shadow_of(ab.sh, P.out);
+    const bool w32 = !(P.no_f32 && out16);                  // (no fp32 reader: the bf16 shadow is the result)
 
 #pragma unroll 1
     for (int it = 0; it < NT; ++it) {
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
                 const int io = 16 * it + 4 * lg + r;
                 if (io < L && c < hd) {
                     const size_t idx = (tok0 + io) * P.ldo + h * hd + c;
-                    P.out[idx] = o[r];
+                    if (w32) P.out[idx] = o[r];
                     if (out16) out16[idx] = m2f_bf16_bits(o[r]);
                 }
             }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
         for (int r = ab.cu[ab.B] + wv; r < ab.T; r += NWAVE)
             for (int c = lane; c < hd; c += 64) {
                 const size_t idx = (size_t)r * P.ldo + h * hd + c;
-                P.out[idx] = 0.f;
+                if (w32) P.out[idx] = 0.f;
                 if (out16) out16[idx] = 0;
             }
     }
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
     uint16_t* dq16 = m2f_shadow_of(ab.sh, P.dq);
     uint16_t* dk16 = m2f_shadow_of(ab.sh, P.dk);
     uint16_t* dv16 = m2f_shadow_of(ab.sh, P.dv);
+    const bool w32 = !(P.no_f32 && dq16 && dk16 && dv16);
 
     // ---- orientation X: lane = query row i, registers = keys j  ->  dQ = dS K ----------------------
 #pragma unroll 1
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 const int io = 16 * it + 4 * lg + r;
                 if (io < L && c < hd) {
                     const size_t idx = (tok0 + io) * P.lddq + h * hd + c;
-                    P.dq[idx] = o[r];
+                    if (w32) P.dq[idx] = o[r];
                     if (dq16) dq16[idx] = m2f_bf16_bits(o[r]);
                 }
             }
@@ -538,8 +540,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
                 const int jo = 16 * jt + 4 * lg + r;
                 if (jo < L && c < hd) {
                     const size_t ik = (tok0 + jo) * P.lddk + h * hd + c, iv = (tok0 + jo) * P.lddv + h * hd + c;
-                    P.dk[ik] = dk[r];
-                    P.dv[iv] = dv[r];
+                    if (w32) { P.dk[ik] = dk[r]; P.dv[iv] = dv[r]; }
                     if (dk16) dk16[ik] = m2f_bf16_bits(dk[r]);
                     if (dv16) dv16[iv] = m2f_bf16_bits(dv[r]);
                 }
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) 
         for (int r = ab.cu[ab.B] + wv; r < ab.T; r += NWAVE)
             for (int c = lane; c < hd; c += 64) {
                 const size_t iq = (size_t)r * P.lddq + h * hd + c, ik = (size_t)r * P.lddk + h * hd + c, iv = (size_t)r * P.lddv + h * hd + c;
-                P.dq[iq] = 0.f; P.dk[ik] = 0.f; P.dv[iv] = 0.f;
+                if (w32) { P.dq[iq] = 0.f; P.dk[ik] = 0.f; P.dv[iv] = 0.f; }
                 if (dq16) dq16[iq] = 0;
                 if (dk16) dk16[ik] = 0;
                 if (dv16) dv16[iv] = 0;
@@ -705,6 +706,12 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_long_fwd_kernel(const float* __
     }
 }
 
+// one-round-trip backward: every problem's slabs fit the register form (NV = 2 * Lp/16 float4) and the fifth (O) slab fits LDS
+int attn_bwd_fast(int Lp, int maxW) {
+    static const bool oslab = getenv("M2F_ATTN_BWD_OSLAB") && getenv("M2F_ATTN_BWD_OSLAB")[0] == '1';
+    return (maxW <= 128 && ((size_t)5 * Lp * (maxW + 2) + Lp) * sizeof(float) <= 160 * 1024) ? (oslab ? 1 : 2) : 0;
+}
+
 template <bool BWD>
 hipError_t launch(AttnBatch& ab, hipStream_t stream) {
     if (ab.count <= 0 || ab.count > M2F_ATTN_MAX_PROBLEMS || ab.L < 1 || ab.L > 64) return hipErrorInvalidValue;
@@ -724,8 +731,7 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
     // one-round-trip backward: every problem's slabs fit the register form (NV = 2 * Lp/16 float4) and the fifth (O) slab fits LDS
     // (2 = the default: O never enters LDS, see the kernel; 1 = with an O slab, the form the parked persistent kernels repeat -
     // M2F_ATTN_BWD_OSLAB=1 selects it so that their bit-for-bit tests still compare like with like)
-    static const bool oslab = getenv("M2F_ATTN_BWD_OSLAB") && getenv("M2F_ATTN_BWD_OSLAB")[0] == '1';
-    ab.bwd_fast = (BWD && maxW <= 128 && ((size_t)5 * Lp * (maxW + 2) + Lp) * sizeof(float) <= 160 * 1024) ? (oslab ? 1 : 2) : 0;
+    ab.bwd_fast = BWD ? attn_bwd_fast(Lp, maxW) : 0;
     const size_t lds = (size_t)(BWD ? (ab.bwd_fast == 1 ? 5 : 4) : 3) * Lp * (maxW + 2) * sizeof(float) +
                        (BWD ? (Lp + (ab.bwd_fast == 2 ? 2 * NT * NTHR : 0)) * sizeof(float) : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -752,6 +758,30 @@ hipError_t launch(AttnBatch& ab, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Host-side mirror of the kernels' staging decisions (slab_fast_ok, slab_shadow, attn_bwd_fast): the operands - bits 2 / 4 / 8 =
+// Q / K / V, backward also 16 / 32 = dO / O - that problem `pi` of this launch reads ONLY through their bf16 shadows, for every
+// (dialogue, head).  plan.hip::mark_unread_fp32 drops the fp32 copy of a buffer nobody reads as fp32 on the strength of this.
+int m2f_attn_shadow_only_bits(const AttnBatch& ab, int pi, bool bwd) {
+    if (pi < 0 || pi >= ab.count || ab.L < 1 || ab.L > 64) return 0;
+    const AttnProblem& P = ab.pr[pi];
+    const int NT = (ab.L + 15) / 16, Lp = 16 * NT, NV = 2 * NT, hd = P.hd, W = (hd + 15) & ~15;
+    int maxW = 0;
+    for (int i = 0; i < ab.count; ++i) maxW = std::max(maxW, (ab.pr[i].hd + 15) & ~15);
+    auto fast_ok = [&](const float* src, int ldg) {
+        return ((hd & 3) == 0) && ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (Lp * (W >> 2) <= NTHR * NV);
+    };
+    auto shadowed = [&](const float* p, int ldg, int bit) {
+        if (!(ab.bf16_math & bit) || !p || !ab.sh.shadow || p < ab.sh.ws_base || p >= ab.sh.ws_base + ab.sh.ws_floats) return false;
+        const uint16_t* q = ab.sh.shadow + (p - ab.sh.ws_base);
+        return ((reinterpret_cast<uintptr_t>(q) & 7) == 0) && ((ldg & 3) == 0) && ((hd & 3) == 0);
+    };
+    if (!(fast_ok(P.q, P.ldq) && fast_ok(P.k, P.ldk) && fast_ok(P.v, P.ldv))) return 0;
+    if (bwd && !(attn_bwd_fast(Lp, maxW) && fast_ok(P.dout, P.lddo) && fast_ok(P.out, P.ldo))) return 0;
+    int bits = (shadowed(P.q, P.ldq, 2) ? 2 : 0) | (shadowed(P.k, P.ldk, 4) ? 4 : 0) | (shadowed(P.v, P.ldv, 8) ? 8 : 0);
+    if (bwd) bits |= (shadowed(P.dout, P.lddo, 16) ? 16 : 0) | (shadowed(P.out, P.ldo, 32) ? 32 : 0);
+    return bits;
+}
 
 size_t m2f_attn_probs_elems(int B, int H, int L) {
     const size_t Lp = 16 * ((L + 15) / 16);

@@ -1511,6 +1511,25 @@ hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream) {
                 : launch_cfg16<false, false, 128, 128, 64, 3, false, false, true>(gb, t, stream);
 }
 
+// Will m2f_launch_gemm stage this bf16-mode launch from the operands' bf16 shadows (true), or from their fp32 originals?  (Host-side
+// mirror of the dispatch below, for plan.hip::mark_unread_fp32.)
+bool m2f_gemm_stages_bf16(const GemmBatch& gb, int layout) {
+    const bool a_rc = layout == M2F_LAYOUT_TN, b_rc = layout != M2F_LAYOUT_NT;
+    if (layout == M2F_LAYOUT_NN) {
+        bool all_t = true;
+        for (int i = 0; i < gb.count; ++i)
+            for (int sgm = 0; sgm < 2; ++sgm)
+                if (gb.pr[i].b.k[sgm] && !gb.pr[i].b.qt[sgm]) all_t = false;
+        if (all_t) {
+            GemmBatch t = gb;
+            for (int i = 0; i < t.count; ++i)
+                for (int sgm = 0; sgm < 2; ++sgm) { t.pr[i].b.q[sgm] = t.pr[i].b.qt[sgm]; t.pr[i].b.ldq[sgm] = t.pr[i].b.ldqt[sgm]; }
+            if (src16_ok(t, false, false)) return true;
+        }
+    }
+    return src16_ok(gb, a_rc, b_rc);
+}
+
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream) {
     if (gb.count <= 0 || gb.count > M2F_GEMM_MAX_PROBLEMS) return hipErrorInvalidValue;
     const bool a_rc = layout == M2F_LAYOUT_TN;

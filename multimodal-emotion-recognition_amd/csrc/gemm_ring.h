@@ -76,7 +76,7 @@ __device__ __forceinline__ void ring_lds_barrier() {
 struct RingEpi {
     int M, N, ldc, ldres, ldgate;
     const float* bias; const float* res; const float* gate; float* C; uint16_t* C16;
-    float gscale; uint32_t site, key; bool relu_out, accum, vec, gelu;
+    float gscale; uint32_t site, key; bool relu_out, accum, vec, gelu, no32;
 };
 template <int BM, int BN>
 __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const GemmProblem& P, int m0, int n0) {
@@ -86,6 +86,7 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
     E.C16 = reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c));
     E.gscale = P.gate_scale;
     E.relu_out = P.flags & GF_RELU_OUT; E.accum = P.flags & GF_ACCUM; E.gelu = P.flags & GF_GELU_OUT;
+    E.no32 = (P.flags & GF_NO_F32) && E.C16 && !E.accum;      // C has no fp32 reader: its bf16 shadow is the result
     E.site = P.drop_site; E.key = 0;
     if (E.site) E.key = m2f_site_key(gb.rng, E.site);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -97,7 +98,8 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
 
 // EPI selects the set of term combinations compiled in: 0 = all 16 (dropout site / gate / residual / accumulate), 1 = none
 // (the weight-gradient table), 2 = {-, residual} x {-, GELU} (the in-loop text encoder's launches: 256x128 tiles hold 128
-// accumulator registers, the full set would spill)
+// accumulator registers, the full set would spill - a fifth variant already sends the accumulators to scratch), 3 = bias only,
+// with or without the fp32 store (GF_NO_F32)
 template <int MI, int NI, int BM, int BN, int EPI = 0>
 __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi& E, f32x16 (&acc)[MI][NI], int m0, int n0,
                                               int lane, int wm, int wn, char* ep) {
@@ -109,7 +111,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
     uint16_t* __restrict__ C16 = E.C16;
     const int ldc = E.ldc, ldres = E.ldres, ldgate = E.ldgate;
     const float gscale = E.gscale;
-    const bool relu_out = E.relu_out, accum = E.accum, vec = E.vec;
+    const bool relu_out = E.relu_out, accum = E.accum, vec = E.vec, w32 = !E.no32;
     const uint32_t site = E.site, key = E.key;
     // F = which optional terms this launch has (block-uniform): 1 dropout site, 2 gate, 4 residual, 8 accumulate.  As runtime
     // branches inside the per-element code they made the epilogue ~45 instructions per element (10k cycles per 128x128
@@ -193,7 +195,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = element(ftag, a[p][e], bv[j][e], (F & 4) ? t.r[p][e] : 0.f, (F & 2) ? t.g[p][e] : 1.f, (F & 8) ? t.c[p][e] : 0.f, row, col + e);
-                    *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;
+                    if constexpr (!(F & 32)) *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;      // F & 32: C has no fp32 reader (GF_NO_F32)
                     if (C16) {
                         uint2 hh;
                         hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
@@ -204,19 +206,24 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                 if (b == 0) { M2F_TS(6); }
             }
         };
-        const int fmask = EPI == 1 ? 0 : (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0) | (E.gelu ? 16 : 0);
+        // (bit 32 = no fp32 store; never together with accumulate, which reads C)
+        const int fmask = EPI == 1 ? 0 : (site ? 1 : 0) | (gate ? 2 : 0) | (res ? 4 : 0) | (accum ? 8 : 0) | (E.gelu ? 16 : 0) | (w32 ? 0 : 32);
         if constexpr (EPI == 1) blocks(std::integral_constant<int, 0>{});
         else if constexpr (EPI == 2) {
-            switch (fmask) {                                        // (the launcher admits nothing else: m2f_gemm_ring_ok)
+            switch (fmask & ~32) {                                  // (the launcher admits nothing else: m2f_gemm_ring_ok)
                 case 0: blocks(std::integral_constant<int, 0>{}); break;
                 case 4: blocks(std::integral_constant<int, 4>{}); break;
                 case 16: blocks(std::integral_constant<int, 16>{}); break;
                 default: blocks(std::integral_constant<int, 20>{}); break;
             }
-        } else switch (fmask) {
+        } else if constexpr (EPI == 3) {                            // bias only, with or without the fp32 store (the merged QKV in-projections)
+            if (fmask & 32) blocks(std::integral_constant<int, 32>{});
+            else blocks(std::integral_constant<int, 0>{});
+        } else switch (fmask & ~16) {
 #define M2F_RING_EP(F) case F: blocks(std::integral_constant<int, F>{}); break;
             M2F_RING_EP(0) M2F_RING_EP(1) M2F_RING_EP(2) M2F_RING_EP(3) M2F_RING_EP(4) M2F_RING_EP(5) M2F_RING_EP(6) M2F_RING_EP(7)
             M2F_RING_EP(8) M2F_RING_EP(9) M2F_RING_EP(10) M2F_RING_EP(11) M2F_RING_EP(12) M2F_RING_EP(13) M2F_RING_EP(14) M2F_RING_EP(15)
+            M2F_RING_EP(32) M2F_RING_EP(33) M2F_RING_EP(34) M2F_RING_EP(35) M2F_RING_EP(36) M2F_RING_EP(37) M2F_RING_EP(38) M2F_RING_EP(39)
 #undef M2F_RING_EP
         }
         return;
@@ -234,7 +241,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                         const uint32_t oc = (uint32_t)(row * ldc + col);
                         const float v = element_rt(acc[i][j][r], bias ? bias[col] : 0.f, res ? res[(size_t)((uint32_t)(row * ldres + col))] : 0.f,
                                                 gate ? gate[(size_t)((uint32_t)(row * ldgate + col))] : 1.f, accum ? C[(size_t)oc] : 0.f, row, col);
-                        C[(size_t)oc] = v;
+                        C[(size_t)oc] = v;                                  // (edge tiles keep the fp32 store whatever GF_NO_F32 says)
                         if (C16) C16[(size_t)oc] = m2f_bf16_bits(v);
                     }
                 }

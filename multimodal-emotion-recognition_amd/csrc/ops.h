@@ -20,7 +20,9 @@ enum { M2F_LAYOUT_NT = 0, M2F_LAYOUT_NN = 1, M2F_LAYOUT_TN = 2 };   // fwd / dgr
 enum {
     GF_RELU_A = 1, GF_RELU_B = 2, GF_RELU_OUT = 4, GF_ACCUM = 8,
     GF_VEC_A = 16, GF_VEC_B = 32,    // set by the launcher when 16-byte loads are legal
-    GF_GELU_OUT = 64                 // exact (erf) GELU instead of ReLU in the epilogue (RoBERTa's intermediate.dense)
+    GF_GELU_OUT = 64,                // exact (erf) GELU instead of ReLU in the epilogue (RoBERTa's intermediate.dense)
+    GF_NO_F32 = 128                  // bf16 mode: nobody reads C as fp32 (plan.hip::mark_unread_fp32) - a kernel that writes C's bf16 shadow
+                                     // may leave the fp32 copy unwritten (the ring epilogue does; the other kernels ignore the flag)
     // (fp8 launches, m2f_launch_gemm_fp8: a.q / b.q point at e4m3 bytes, k / ldq count BYTE PAIRS, the accumulator is
     //  multiplied by acc_scale = 1 / (scale_a * scale_b) before the epilogue terms)
 };
@@ -106,6 +108,7 @@ struct GemmBatch {
 #define M2F_SPLITK_MAX_TILES 512
 
 // RING form of the k-contiguous bf16 GEMM (gemm_ring.h): bm x bn = 128x128 or 128x64; the table form walks gb.table.
+bool m2f_gemm_stages_bf16(const GemmBatch& gb, int layout);      // host: does the bf16-mode launch read bf16 shadows only?
 bool m2f_gemm_ring_ok(const GemmBatch& gb);
 bool m2f_gemm_ring256_ok(const GemmBatch& gb);       // 256x128 tiles: bias / ReLU / GELU / residual epilogues only
 hipError_t m2f_launch_gemm_ring(GemmBatch& gb, int bm, int bn, hipStream_t stream);
@@ -148,6 +151,7 @@ struct AttnProblem {
     int H, hd;
     uint32_t drop_site;
     int block_begin;                                   // filled by the launcher
+    uint32_t no_f32;                                   // bf16 mode: out (fwd) / dq, dk, dv (bwd) have no fp32 reader - only their bf16 shadows are written
 };
 #define M2F_ATTN_MAX_PROBLEMS 4
 struct AttnBatch {
@@ -167,6 +171,7 @@ struct AttnBatch {
                                // on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): 1/8 of the MFMA instructions at 1/2 the cycles each;
                                // 2 / 4 / 8 / 16 / 32 = the Q / K / V / dO / O slab is staged from the operand's bf16 shadow (half the bytes)
 };
+int m2f_attn_shadow_only_bits(const AttnBatch& ab, int pi, bool bwd);     // host: operands this launch stages from bf16 shadows only
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
 // Long-sequence forward (S unbounded, hd <= 128): token-level self-attention of the in-loop text encoder (inference).
 // q/k/v rows are token-major (token t = b*S + i), head h in columns [h*hd, (h+1)*hd); key_pad [B, S] (1 = padded, nullable).

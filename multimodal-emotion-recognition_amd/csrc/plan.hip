@@ -274,6 +274,7 @@ struct m2f_plan {
     // all-reduce can travel under part 1.  Same table, two tile lists.
     size_t bwd_head = 0;
     bool split_ok = false;
+    int n_no_f32 = 0;                    // outputs whose fp32 copy is not written (mark_unread_fp32)
     int64_t split_offset = 0;
     GemmBatch wg_tab_part[2];
     size_t wg_rest_head = 0;             // wg_rest[0, wg_rest_head) belong to part 0
@@ -1056,6 +1057,130 @@ void build_mega(m2f_plan& P, Arena& ar, bool real) {
     if (real && prof) (void)hipMemset(prof, 0, 128 * sizeof(unsigned long long));
 }
 
+// bf16 mode: which fp32 results does nobody read?  Every GEMM / attention output in the workspace is written twice - fp32 and
+// its bf16 shadow - but GEMM operands, the weight-gradient table and (M2F_ATTN_BF16 bits) the attention slabs are staged from the
+// shadows: the fp32 copy of a QKV projection, an attention output, an attention input gradient or an FFN hidden gradient is
+// dead weight (half a gigabyte of writes per C3 step).  The readers are enumerated from the FINAL launch lists - whatever takes a
+// workspace pointer as fp32 marks its extent in a map of 64-float blocks - and an output whose extent holds no mark gets
+// GF_NO_F32 / AttnProblem::no_f32.  Its fp32 buffer is then filled with NaNs, once: a reader this walk does not know about
+// cannot go unnoticed.  M2F_SKIP_F32=0 (read when a plan is built) keeps every fp32 store.
+int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, bool poison) {
+    const char* e = getenv("M2F_SKIP_F32");
+    if (e && atoi(e) == 0) return 0;
+    std::vector<uint8_t> read32((ws_floats + 63) / 64, 0);
+    auto span = [&](const float* p, size_t rows, size_t ld, size_t cols, size_t& lo, size_t& hi) {
+        if (!p || p < wsf || p >= wsf + ws_floats || rows == 0) return false;
+        lo = (size_t)(p - wsf); hi = std::min(ws_floats, lo + (rows - 1) * ld + cols);
+        return hi > lo;
+    };
+    auto mark = [&](const float* p, size_t rows, size_t ld, size_t cols) {
+        size_t lo, hi;
+        if (span(p, rows, ld, cols, lo, hi)) for (size_t b = lo / 64; b <= (hi - 1) / 64; ++b) read32[b] = 1;
+    };
+    auto unread = [&](const float* p, size_t rows, size_t ld, size_t cols) {
+        size_t lo, hi;
+        if (!span(p, rows, ld, cols, lo, hi)) return false;
+        for (size_t b = lo / 64; b <= (hi - 1) / 64; ++b) if (read32[b]) return false;
+        return true;
+    };
+    const size_t T = (size_t)P.T;
+    // buffers the caller sees (m2f_plan_buffer): always fp32-read
+    auto pad8 = [](int x) { return (size_t)((x + 7) & ~7); };
+    mark(static_cast<const float*>(P.bufs[M2F_BUF_TEXT]), T, pad8(P.cfg.d_text), pad8(P.cfg.d_text));
+    mark(static_cast<const float*>(P.bufs[M2F_BUF_AUDIO]), T, pad8(P.cfg.d_audio), pad8(P.cfg.d_audio));
+    mark(static_cast<const float*>(P.bufs[M2F_BUF_LOGITS]), T, (size_t)P.cfg.cls_out, (size_t)P.cfg.cls_out);
+    mark(static_cast<const float*>(P.bufs[M2F_BUF_DLOGITS]), T, (size_t)P.cfg.cls_out, (size_t)P.cfg.cls_out);
+    mark(static_cast<const float*>(P.bufs[M2F_BUF_FAM0_OUT]), T, pad8(P.cfg.d_fam), pad8(P.cfg.d_fam));
+    auto operand = [&](const GemmOperand& o, size_t rows_hint, bool launch16) {
+        for (int sg = 0; sg < 2; ++sg)
+            if (o.k[sg] > 0 && o.p[sg] && (!launch16 || !o.q[sg]))      // staged from fp32 (extent: generous)
+                mark(o.p[sg], std::max(rows_hint, (size_t)o.k[sg]), (size_t)o.ld[sg], (size_t)o.ld[sg]);
+    };
+    std::vector<std::vector<Launch>*> lists = {&P.fwd, &P.bwd, &P.wg_rest};
+    for (std::vector<Launch>* ls : lists)
+        for (Launch& l : *ls) {
+            switch (l.kind) {
+                case OP_GEMM: {
+                    const bool launch16 = m2f_gemm_stages_bf16(l.gb, l.layout);      // (one operand without a shadow sends the whole launch to fp32 staging)
+                    for (int i = 0; i < l.gb.count; ++i) {
+                        const GemmProblem& g = l.gb.pr[i];
+                        const size_t big = (size_t)std::max(std::max(g.M, g.N), (int)T);
+                        operand(g.a, big, launch16); operand(g.b, big, launch16);
+                        mark(g.res, (size_t)g.M, (size_t)g.ldres, (size_t)g.N);
+                        mark(g.gate, (size_t)g.M, (size_t)g.ldgate, (size_t)g.N);
+                        if (g.flags & GF_ACCUM) mark(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N);
+                    }
+                    break;
+                }
+                case OP_ATTN_FWD: case OP_ATTN_BWD:
+                    for (int i = 0; i < l.ab.count; ++i) {
+                        const AttnProblem& a = l.ab.pr[i];
+                        const size_t w = (size_t)a.H * a.hd;
+                        const int bits = m2f_attn_shadow_only_bits(l.ab, i, l.kind == OP_ATTN_BWD);
+                        if (!(bits & 2)) mark(a.q, T, (size_t)a.ldq, w);
+                        if (!(bits & 4)) mark(a.k, T, (size_t)a.ldk, w);
+                        if (!(bits & 8)) mark(a.v, T, (size_t)a.ldv, w);
+                        if (l.kind == OP_ATTN_BWD) {
+                            if (!(bits & 16)) mark(a.dout, T, (size_t)a.lddo, w);
+                            if (!(bits & 32)) mark(a.out, T, (size_t)a.ldo, w);
+                        }
+                    }
+                    break;
+                case OP_LN_FWD: case OP_LN_BWD:
+                    for (int i = 0; i < l.lb.count; ++i) {
+                        const LnProblem& q = l.lb.pr[i];
+                        const size_t ld = (size_t)(q.ld ? q.ld : q.d);
+                        mark(q.x, T, ld, (size_t)q.d);
+                        mark(q.res, T, ld, (size_t)q.d);
+                        if (l.kind == OP_LN_BWD) { mark(q.dy, T, ld, (size_t)q.d); mark(q.extra, T, ld, (size_t)q.d); }
+                    }
+                    break;
+                case OP_DROPOUT: mark(l.dptr, (size_t)l.dT, (size_t)l.dld, (size_t)l.dd); break;
+                default: break;
+            }
+        }
+    for (const CastBatch& cb : P.wg_casts)
+        for (int i = 0; i < cb.count; ++i) mark(cb.it[i].src, (size_t)cb.it[i].rows, (size_t)cb.it[i].lds, (size_t)cb.it[i].cols);
+    // (the weight-gradient table stages bf16 shadows only - what it cannot take went to wg_rest / wg_casts above; the criterion
+    // reads the logits, marked with the caller-visible buffers)
+    int n = 0;
+    auto poison_buf = [&](float* p, size_t rows, size_t ld, size_t cols) {
+        size_t lo, hi;
+        if (!poison || !span(p, rows, ld, cols, lo, hi)) return 0;
+        return hipMemset(p, 0xFF, (hi - lo) * sizeof(float)) == hipSuccess ? 0 : 1;
+    };
+    for (std::vector<Launch>* ls : {&P.fwd, &P.bwd})
+        for (Launch& l : *ls) {
+            if (l.kind == OP_GEMM) {
+                for (int i = 0; i < l.gb.count; ++i) {
+                    GemmProblem& g = l.gb.pr[i];
+                    if ((g.flags & GF_ACCUM) || g.c8 || !unread(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) continue;
+                    g.flags |= GF_NO_F32; ++n;
+                    if (poison_buf(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) return fail("mark_unread_fp32: hipMemset");
+                }
+            } else if (l.kind == OP_ATTN_FWD) {
+                for (int i = 0; i < l.ab.count; ++i) {
+                    AttnProblem& a = l.ab.pr[i];
+                    const size_t w = (size_t)a.H * a.hd;
+                    if (!unread(a.out, T, (size_t)a.ldo, w)) continue;
+                    a.no_f32 = 1; ++n;
+                    if (poison_buf(a.out, T, (size_t)a.ldo, w)) return fail("mark_unread_fp32: hipMemset");
+                }
+            } else if (l.kind == OP_ATTN_BWD) {
+                for (int i = 0; i < l.ab.count; ++i) {
+                    AttnProblem& a = l.ab.pr[i];
+                    const size_t w = (size_t)a.H * a.hd;
+                    if (!unread(a.dq, T, (size_t)a.lddq, w) || !unread(a.dk, T, (size_t)a.lddk, w) || !unread(a.dv, T, (size_t)a.lddv, w)) continue;
+                    a.no_f32 = 1; ++n;
+                    if (poison_buf(a.dq, T, (size_t)a.lddq, w) || poison_buf(a.dk, T, (size_t)a.lddk, w) || poison_buf(a.dv, T, (size_t)a.lddv, w))
+                        return fail("mark_unread_fp32: hipMemset");
+                }
+            }
+        }
+    P.n_no_f32 = n;
+    return 0;
+}
+
 int build_plan(m2f_plan& P, char* ws_base) {
     const m2f_config& c = P.cfg;
     Builder bld(P);
@@ -1369,6 +1494,9 @@ int build_plan(m2f_plan& P, char* ws_base) {
             cb.it[cb.count++] = {x, shadow + (x - wsf), T, c.d_audio, dp, dp, nullptr, 0};
         }
         flush();
+    }
+    if (P.prec == M2F_PREC_BF16 && ws_base != nullptr && (!P.train || (table_ok && table_rc))) {
+        if (int r = mark_unread_fp32(P, reinterpret_cast<const float*>(ws_base), ws_floats, true)) return r;
     }
     build_mega(P, bld.ar, ws_base != nullptr);
     P.ws_used = bld.ar.off;

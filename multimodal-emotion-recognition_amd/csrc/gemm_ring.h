@@ -83,7 +83,7 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
     RingEpi E;
     E.M = P.M; E.N = P.N; E.ldc = P.ldc; E.ldres = P.ldres; E.ldgate = P.ldgate;
     E.bias = P.bias; E.res = P.res; E.gate = P.gate; E.C = P.c;
-    E.C16 = reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c));
+    E.C16 = (P.flags & GF_NO_BF16) ? nullptr : reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c));
     E.gscale = P.gate_scale;
     E.relu_out = P.flags & GF_RELU_OUT; E.accum = P.flags & GF_ACCUM; E.gelu = P.flags & GF_GELU_OUT;
     E.no32 = (P.flags & GF_NO_F32) && E.C16 && !E.accum;      // C has no fp32 reader: its bf16 shadow is the result

@@ -21,6 +21,7 @@ enum {
     GF_RELU_A = 1, GF_RELU_B = 2, GF_RELU_OUT = 4, GF_ACCUM = 8,
     GF_VEC_A = 16, GF_VEC_B = 32,    // set by the launcher when 16-byte loads are legal
     GF_GELU_OUT = 64,                // exact (erf) GELU instead of ReLU in the epilogue (RoBERTa's intermediate.dense)
+    GF_NO_BF16 = 256,                // bf16 mode: nobody stages C from its bf16 shadow (a residual term, a LayerNorm input): the ring epilogue skips it
     GF_NO_F32 = 128                  // bf16 mode: nobody reads C as fp32 (plan.hip::mark_unread_fp32) - a kernel that writes C's bf16 shadow
                                      // may leave the fp32 copy unwritten (the ring epilogue does; the other kernels ignore the flag)
     // (fp8 launches, m2f_launch_gemm_fp8: a.q / b.q point at e4m3 bytes, k / ldq count BYTE PAIRS, the accumulator is
@@ -197,6 +198,9 @@ struct LnProblem {
     float* partial;                    // [n_row_blocks, 2, d] partial (dgamma, dbeta)
     uint32_t drop_site2;
     int block_begin;
+    // bf16 mode, set by plan.hip::mark_unread_fp32 - copies nobody reads: 1 = dx_masked as fp32 (only GEMMs stage it, from its
+    // shadow), 2 = dx as bf16 (it is only a residual term / a LayerNorm input)
+    uint32_t skip;
 };
 #define M2F_LN_MAX_PROBLEMS 4
 struct LnBatch {

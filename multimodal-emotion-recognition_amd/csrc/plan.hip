@@ -1064,10 +1064,12 @@ void build_mega(m2f_plan& P, Arena& ar, bool real) {
 // workspace pointer as fp32 marks its extent in a map of 64-float blocks - and an output whose extent holds no mark gets
 // GF_NO_F32 / AttnProblem::no_f32.  Its fp32 buffer is then filled with NaNs, once: a reader this walk does not know about
 // cannot go unnoticed.  M2F_SKIP_F32=0 (read when a plan is built) keeps every fp32 store.
-int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, bool poison) {
+int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, const std::vector<GemmProblem>& table_probs, bool poison) {
     const char* e = getenv("M2F_SKIP_F32");
     if (e && atoi(e) == 0) return 0;
-    std::vector<uint8_t> read32((ws_floats + 63) / 64, 0);
+    const char* mg = getenv("M2F_MEGA");
+    if (mg && mg[0] == '1') return 0;                 // (the parked persistent kernels read the fp32 buffers)
+    std::vector<uint8_t> read32((ws_floats + 63) / 64, 0), read16((ws_floats + 63) / 64, 0);      // fp32 readers / bf16-shadow readers
     auto span = [&](const float* p, size_t rows, size_t ld, size_t cols, size_t& lo, size_t& hi) {
         if (!p || p < wsf || p >= wsf + ws_floats || rows == 0) return false;
         lo = (size_t)(p - wsf); hi = std::min(ws_floats, lo + (rows - 1) * ld + cols);
@@ -1076,6 +1078,18 @@ int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, bool poiso
     auto mark = [&](const float* p, size_t rows, size_t ld, size_t cols) {
         size_t lo, hi;
         if (span(p, rows, ld, cols, lo, hi)) for (size_t b = lo / 64; b <= (hi - 1) / 64; ++b) read32[b] = 1;
+    };
+    const uint16_t* sh0 = P.sh.shadow;
+    auto mark16 = [&](const uint16_t* q, size_t rows, size_t ld, size_t cols) {      // q: a pointer into the activation shadow
+        if (!q || !sh0 || q < sh0 || q >= sh0 + ws_floats) return;
+        size_t lo, hi;
+        if (span(wsf + (q - sh0), rows, ld, cols, lo, hi)) for (size_t b = lo / 64; b <= (hi - 1) / 64; ++b) read16[b] = 1;
+    };
+    auto unread16 = [&](const float* p, size_t rows, size_t ld, size_t cols) {
+        size_t lo, hi;
+        if (!span(p, rows, ld, cols, lo, hi)) return false;
+        for (size_t b = lo / 64; b <= (hi - 1) / 64; ++b) if (read16[b]) return false;
+        return true;
     };
     auto unread = [&](const float* p, size_t rows, size_t ld, size_t cols) {
         size_t lo, hi;
@@ -1093,8 +1107,11 @@ int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, bool poiso
     mark(static_cast<const float*>(P.bufs[M2F_BUF_FAM0_OUT]), T, pad8(P.cfg.d_fam), pad8(P.cfg.d_fam));
     auto operand = [&](const GemmOperand& o, size_t rows_hint, bool launch16) {
         for (int sg = 0; sg < 2; ++sg)
-            if (o.k[sg] > 0 && o.p[sg] && (!launch16 || !o.q[sg]))      // staged from fp32 (extent: generous)
-                mark(o.p[sg], std::max(rows_hint, (size_t)o.k[sg]), (size_t)o.ld[sg], (size_t)o.ld[sg]);
+            if (o.k[sg] > 0 && o.p[sg]) {
+                const size_t rows = std::max(rows_hint, (size_t)o.k[sg]);
+                if (!launch16 || !o.q[sg]) mark(o.p[sg], rows, (size_t)o.ld[sg], (size_t)o.ld[sg]);      // staged from fp32 (extent: generous)
+                else mark16(o.q[sg], rows, (size_t)o.ldq[sg], (size_t)o.ldq[sg]);
+            }
     };
     std::vector<std::vector<Launch>*> lists = {&P.fwd, &P.bwd, &P.wg_rest};
     for (std::vector<Launch>* ls : lists)
@@ -1117,13 +1134,12 @@ int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, bool poiso
                         const AttnProblem& a = l.ab.pr[i];
                         const size_t w = (size_t)a.H * a.hd;
                         const int bits = m2f_attn_shadow_only_bits(l.ab, i, l.kind == OP_ATTN_BWD);
-                        if (!(bits & 2)) mark(a.q, T, (size_t)a.ldq, w);
-                        if (!(bits & 4)) mark(a.k, T, (size_t)a.ldk, w);
-                        if (!(bits & 8)) mark(a.v, T, (size_t)a.ldv, w);
-                        if (l.kind == OP_ATTN_BWD) {
-                            if (!(bits & 16)) mark(a.dout, T, (size_t)a.lddo, w);
-                            if (!(bits & 32)) mark(a.out, T, (size_t)a.ldo, w);
-                        }
+                        auto rd = [&](const float* p, int ld, int bit) {
+                            if (!p) return;
+                            if (bits & bit) mark16(sh0 + (p - wsf), T, (size_t)ld, w); else mark(p, T, (size_t)ld, w);
+                        };
+                        rd(a.q, a.ldq, 2); rd(a.k, a.ldk, 4); rd(a.v, a.ldv, 8);
+                        if (l.kind == OP_ATTN_BWD) { rd(a.dout, a.lddo, 16); rd(a.out, a.ldo, 32); }
                     }
                     break;
                 case OP_LN_FWD: case OP_LN_BWD:
@@ -1143,20 +1159,46 @@ int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, bool poiso
         for (int i = 0; i < cb.count; ++i) mark(cb.it[i].src, (size_t)cb.it[i].rows, (size_t)cb.it[i].lds, (size_t)cb.it[i].cols);
     // (the weight-gradient table stages bf16 shadows only - what it cannot take went to wg_rest / wg_casts above; the criterion
     // reads the logits, marked with the caller-visible buffers)
+    for (const GemmProblem& g : table_probs) {
+        mark16(g.a.q[0], T, (size_t)g.a.ldq[0], (size_t)g.a.ldq[0]);
+        mark16(g.b.q[0], T, (size_t)g.b.ldq[0], (size_t)g.b.ldq[0]);
+    }
     int n = 0;
     auto poison_buf = [&](float* p, size_t rows, size_t ld, size_t cols) {
         size_t lo, hi;
         if (!poison || !span(p, rows, ld, cols, lo, hi)) return 0;
         return hipMemset(p, 0xFF, (hi - lo) * sizeof(float)) == hipSuccess ? 0 : 1;
     };
+    auto poison16 = [&](const float* p, size_t rows, size_t ld, size_t cols) {       // ... and a shadow that is no longer written
+        size_t lo, hi;
+        if (!poison || !sh0 || !span(p, rows, ld, cols, lo, hi)) return 0;
+        return hipMemset(const_cast<uint16_t*>(sh0) + lo, 0xFF, (hi - lo) * sizeof(uint16_t)) == hipSuccess ? 0 : 1;
+    };
     for (std::vector<Launch>* ls : {&P.fwd, &P.bwd})
         for (Launch& l : *ls) {
             if (l.kind == OP_GEMM) {
                 for (int i = 0; i < l.gb.count; ++i) {
                     GemmProblem& g = l.gb.pr[i];
-                    if ((g.flags & GF_ACCUM) || g.c8 || !unread(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) continue;
+                    if (unread16(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) {      // nobody stages C's shadow
+                        g.flags |= GF_NO_BF16; ++n;
+                        if (poison16(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) return fail("mark_unread_fp32: hipMemset");
+                    }
+                    if ((g.flags & (GF_ACCUM | GF_NO_BF16)) || g.c8 || !unread(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) continue;
                     g.flags |= GF_NO_F32; ++n;
                     if (poison_buf(g.c, (size_t)g.M, (size_t)g.ldc, (size_t)g.N)) return fail("mark_unread_fp32: hipMemset");
+                }
+            } else if (l.kind == OP_LN_BWD) {
+                for (int i = 0; i < l.lb.count; ++i) {
+                    LnProblem& q = l.lb.pr[i];
+                    const size_t ld = (size_t)(q.ld ? q.ld : q.d);
+                    if (q.dx_masked && unread(q.dx_masked, T, ld, (size_t)q.d)) {
+                        q.skip |= 1u; ++n;
+                        if (poison_buf(q.dx_masked, T, ld, (size_t)q.d)) return fail("mark_unread_fp32: hipMemset");
+                    }
+                    if (unread16(q.dx, T, ld, (size_t)q.d)) {
+                        q.skip |= 2u; ++n;
+                        if (poison16(q.dx, T, ld, (size_t)q.d)) return fail("mark_unread_fp32: hipMemset");
+                    }
                 }
             } else if (l.kind == OP_ATTN_FWD) {
                 for (int i = 0; i < l.ab.count; ++i) {
@@ -1496,7 +1538,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
         flush();
     }
     if (P.prec == M2F_PREC_BF16 && ws_base != nullptr && (!P.train || (table_ok && table_rc))) {
-        if (int r = mark_unread_fp32(P, reinterpret_cast<const float*>(ws_base), ws_floats, true)) return r;
+        if (int r = mark_unread_fp32(P, reinterpret_cast<const float*>(ws_base), ws_floats, tprobs, true)) return r;
     }
     build_mega(P, bld.ar, ws_base != nullptr);
     P.ws_used = bld.ar.off;

@@ -77,7 +77,7 @@ __device__ __forceinline__ bool is_vec(const void* p, int d) {
 
 template <int NV>
 __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
-    m2f_kernarg_warm<0, 8, 72>();                   // the descriptor block (520 B + hidden arguments) in one miss
+    m2f_kernarg_warm<0, 8, 136>();                  // the descriptor block (520 B + hidden arguments) in one miss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pi = 0;
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
 
 template <int NV>
 __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
-    m2f_kernarg_warm<0, 8, 72>();                   // the descriptor block (520 B + hidden arguments) in one miss
+    m2f_kernarg_warm<0, 8, 136>();                  // the descriptor block (520 B + hidden arguments) in one miss
     extern __shared__ __attribute__((aligned(16))) float red[];      // [LN_WAVES][2][dpad]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pi = 0;
@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
     const int blk = (int)blockIdx.x - P.block_begin;
     const bool vec = is_vec(P.x, d) && is_vec(P.dy, d) && is_vec(P.dx, d) && is_vec(P.gamma, d) &&
                      (!P.extra || is_vec(P.extra, d)) && (!P.dx_masked || is_vec(P.dx_masked, d)) && ((ld & 3) == 0);
-    uint16_t* dx16 = m2f_shadow_of(lb.sh, P.dx);
+    uint16_t* dx16 = (P.skip & 2) ? nullptr : m2f_shadow_of(lb.sh, P.dx);
     uint16_t* dxm16 = P.dx_masked ? m2f_shadow_of(lb.sh, P.dx_masked) : nullptr;
+    const bool dxm32 = P.dx_masked && !((P.skip & 1) && dxm16);
     RowRegs<NV> g, dg, db;
     row_load(g, P.gamma, d, vec, lane);
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
             }
         row_store(dy, P.dx + (size_t)row * ld, d, vec, lane);
         if (dx16) row_store_bf16(dy, dx16 + (size_t)row * ld, d, lane);
-        if (P.dx_masked) row_store(msk, P.dx_masked + (size_t)row * ld, d, vec, lane);
+        if (dxm32) row_store(msk, P.dx_masked + (size_t)row * ld, d, vec, lane);
         if (dxm16) row_store_bf16(msk, dxm16 + (size_t)row * ld, d, lane);
     }
     // per-block partial dgamma / dbeta: waves -> LDS -> fixed-order sum (deterministic)

@@ -182,6 +182,14 @@ int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* gr
                            uint16_t* param_shadow, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                            const float* grad_scale_ptr, m2f_stream_t stream);
 
+/* bf16-mode plans write every activation twice - fp32 and the bf16 shadow the GEMMs / attention kernels stage from.  When a plan
+ * is built, the readers of every workspace buffer are enumerated from its final launch lists; a copy nobody reads is not written
+ * (fp32 of QKV projections, attention outputs, their gradients and the FFN hidden gradients; the shadows of results that are only
+ * residual terms or LayerNorm inputs), and its buffer is filled with NaNs once so
+ * that an unknown reader cannot go unnoticed.  Returns how many copies this plan skips (0: fp32 mode, or M2F_SKIP_F32=0 when the
+ * plan was built).  Results are bit-identical either way.  No counterpart in the reference (autocast keeps one copy per tensor). */
+int m2f_plan_skipped_copies(m2f_plan* plan);
+
 /* ---- in-loop text encoder (BASELINE config C5) -------------------------------------------------
  * The reference computes its text embeddings with transformers' RobertaModel (src/feature_extractors/text/model.py:16-21,
  * [CLS] pooling at text/embeddings.py:83) in a separate stage; these entry points are the pieces that model needs beyond

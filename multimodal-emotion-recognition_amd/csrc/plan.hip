@@ -1879,6 +1879,8 @@ int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* gr
     return 0;
 }
 
+int m2f_plan_skipped_copies(m2f_plan* plan) { return plan ? plan->n_no_f32 : -1; }
+
 int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
     if (!plan || !out8) return fail("m2f_plan_status: NULL plan (destroyed?) or output");
     for (int i = 0; i < 8; ++i) out8[i] = 0u;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "m2f_plan_params_fresh": (c_int, [c_void_p, c_int]),
     "m2f_adam_step_shadowed": (c_int, [ctypes.POINTER(M2FConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                        c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "m2f_plan_skipped_copies": (c_int, [c_void_p]),
     "m2f_plan_destroy": (None, [c_void_p]),
     "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
     "m2f_plan_num_launches": (c_int, [c_void_p, c_int]),
@@ -436,6 +437,10 @@ class Plan:
                              stream_ptr()), "m2f_step")
         self._casted()
         return self.loss
+
+    def skipped_copies(self) -> int:
+        """How many fp32 / bf16 copies of activations this plan does not write because nobody reads them (bf16 mode)."""
+        return int(lib().m2f_plan_skipped_copies(self._h()))
 
     def split_offset(self) -> int:
         """First element of the flat gradient buffer that is final after `step_part(0)` (0: this plan cannot be split)."""

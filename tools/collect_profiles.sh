@@ -18,5 +18,6 @@ tools/pmc_bench.sh "ring_kernel<128, 64" --workload c3 --secondary none > $O/pmc
 tools/pmc_bench.sh "ring_kernel<128, 128, 4, false" --workload c3 --secondary none > $O/pmc_ring_128x128_c3.txt 2>&1
 tools/pmc_bench.sh "ring_kernel<256, 128, 3, true" --workload c3 --secondary none > $O/pmc_ring_table_rc_256x128_c3.txt 2>&1
 tools/pmc_bench.sh "m2f_attn_bwd" --workload c3 --secondary none > $O/pmc_attn_bwd_c3.txt 2>&1
+tools/pmc_bench.sh "m2f_ln_bwd" --workload c3 --secondary none > $O/pmc_ln_bwd_c3.txt 2>&1
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo done > $O/DONE

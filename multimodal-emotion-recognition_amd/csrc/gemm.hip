@@ -1489,6 +1489,8 @@ hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+hipError_t m2f_ring_launch_256x128_fp8(GemmBatch& gb, hipStream_t stream);      // gemm_ring_256x128_fp8.hip
+
 hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream) {
     if (gb.count != 1) return hipErrorInvalidValue;
     GemmProblem& p = gb.pr[0];
@@ -1499,6 +1501,13 @@ hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream) {
     // the staging code moves 16-byte chunks of a row whatever they hold: hand it the rows in byte pairs
     p.a.k[0] >>= 1; p.b.k[0] >>= 1; p.a.ldq[0] >>= 1; p.b.ldq[0] >>= 1;
     const bool gelu = p.flags & GF_GELU_OUT;
+    {   // the ring form (gemm_ring_256x128_fp8.hip) from one chip-filling round of 256x128 tiles on; M2F_RING_FP8=0 keeps the register-staged build
+        static const int ring8 = getenv("M2F_RING_FP8") ? atoi(getenv("M2F_RING_FP8")) : 1;
+        const bool small = (size_t)p.M * p.a.ldq[0] * 2 < 0x80000000ull && (size_t)p.N * p.b.ldq[0] * 2 < 0x80000000ull;
+        const bool whole = p.M % 256 == 0 && p.N % 128 == 0;       // (the ring epilogue writes e4m3 results of whole tiles only)
+        if (ring8 && small && m2f_cdiv(p.M, 256) * m2f_cdiv(p.N, 128) >= 256 && !(p.flags & GF_RELU_OUT) && (!p.c8 || whole))
+            return m2f_ring_launch_256x128_fp8(gb, stream);
+    }
     int tile_m = 256, tile_n = 128;
     if (m2f_cdiv(p.M, 256) * m2f_cdiv(p.N, 128) < 1024) { tile_m = 128; tile_n = 128; }
     p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0; p.tile_begin = 0;

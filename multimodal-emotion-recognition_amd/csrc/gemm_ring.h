@@ -77,6 +77,7 @@ struct RingEpi {
     int M, N, ldc, ldres, ldgate;
     const float* bias; const float* res; const float* gate; float* C; uint16_t* C16;
     float gscale; uint32_t site, key; bool relu_out, accum, vec, gelu, no32;
+    float acc_scale, c8_scale; uint8_t* c8;      // fp8 launches (EPI 4): de-quantisation factor; e4m3 result instead of fp32 C
 };
 template <int BM, int BN>
 __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const GemmProblem& P, int m0, int n0) {
@@ -87,10 +88,11 @@ __device__ __forceinline__ RingEpi ring_epilogue_args(const GemmBatch& gb, const
     E.gscale = P.gate_scale;
     E.relu_out = P.flags & GF_RELU_OUT; E.accum = P.flags & GF_ACCUM; E.gelu = P.flags & GF_GELU_OUT;
     E.no32 = (P.flags & GF_NO_F32) && E.C16 && !E.accum;      // C has no fp32 reader: its bf16 shadow is the result
+    E.acc_scale = P.acc_scale; E.c8_scale = P.c8_scale; E.c8 = P.c8;
     E.site = P.drop_site; E.key = 0;
     if (E.site) E.key = m2f_site_key(gb.rng, E.site);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    E.vec = (m0 + BM <= E.M) && (n0 + BN <= E.N) && al16(E.C) && ((E.ldc & 3) == 0) && (!E.bias || al16(E.bias)) &&
+    E.vec = (m0 + BM <= E.M) && (n0 + BN <= E.N) && (E.c8 ? ((reinterpret_cast<uintptr_t>(E.c8) & 3) == 0) : al16(E.C)) && ((E.ldc & 3) == 0) && (!E.bias || al16(E.bias)) &&
             (!E.res || (al16(E.res) && (E.ldres & 3) == 0)) && (!E.gate || (al16(E.gate) && (E.ldgate & 3) == 0)) &&
             (!E.C16 || (reinterpret_cast<uintptr_t>(E.C16) & 7) == 0);                  // block-uniform
     return E;
@@ -109,6 +111,8 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
     const float* __restrict__ gate = E.gate;
     float* __restrict__ C = E.C;
     uint16_t* __restrict__ C16 = E.C16;
+    uint8_t* __restrict__ c8 = EPI == 4 ? E.c8 : nullptr;
+    const float c8s = E.c8_scale;
     const int ldc = E.ldc, ldres = E.ldres, ldgate = E.ldgate;
     const float gscale = E.gscale;
     const bool relu_out = E.relu_out, accum = E.accum, vec = E.vec, w32 = !E.no32;
@@ -119,7 +123,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
     // absent terms cost nothing - no instructions, no registers.
     auto element = [&](auto ftag, float a, float bv, float rv, float gv, float cv, int row, int col) {
         constexpr int F = decltype(ftag)::value;
-        float x = a + bv;
+        float x = (EPI == 4 ? a * E.acc_scale : a) + bv;
         x = relu_out ? fmaxf(x, 0.f) : x;
         if constexpr (F & 16) x = m2f_gelu<true>(x);                 // (the polynomial erf of the bf16 kernels, gemm.hip)
         if constexpr (F & 1) x = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? x * gb.drop_scale : 0.f;
@@ -128,9 +132,9 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
         if constexpr (F & 8) return x + cv; else return x + 0.f;
     };
     auto element_rt = [&](float a, float bv, float rv, float gv, float cv, int row, int col) {      // edge tiles
-        float x = a + bv;
+        float x = (EPI == 4 ? a * E.acc_scale : a) + bv;
         if (relu_out) x = fmaxf(x, 0.f);
-        if (EPI == 2 && E.gelu) x = m2f_gelu<true>(x);
+        if ((EPI == 2 || EPI == 4) && E.gelu) x = m2f_gelu<true>(x);
         if (site) x = m2f_keep(key, (uint32_t)row * (uint32_t)N + (uint32_t)col, gb.drop_thresh) ? x * gb.drop_scale : 0.f;
         x = x + rv;
         if (gate) x = gv > 0.f ? x * gscale : 0.f;
@@ -195,7 +199,10 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = element(ftag, a[p][e], bv[j][e], (F & 4) ? t.r[p][e] : 0.f, (F & 2) ? t.g[p][e] : 1.f, (F & 8) ? t.c[p][e] : 0.f, row, col + e);
-                    if constexpr (!(F & 32)) *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;      // F & 32: C has no fp32 reader (GF_NO_F32)
+                    if constexpr (EPI == 4) {                        // fp8 launches: e4m3(result * c8_scale) instead of fp32 C (block-uniform), no shadow
+                        if (c8) *reinterpret_cast<uint32_t*>(c8 + (size_t)oc) = m2f_fp8x4_bits(v[0] * c8s, v[1] * c8s, v[2] * c8s, v[3] * c8s);
+                        else *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;
+                    } else if constexpr (!(F & 32)) *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;      // F & 32: C has no fp32 reader (GF_NO_F32)
                     if (C16) {
                         uint2 hh;
                         hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
@@ -211,6 +218,13 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
         if constexpr (EPI == 1) blocks(std::integral_constant<int, 0>{});
         else if constexpr (EPI == 2) {
             switch (fmask & ~32) {                                  // (the launcher admits nothing else: m2f_gemm_ring_ok)
+                case 0: blocks(std::integral_constant<int, 0>{}); break;
+                case 4: blocks(std::integral_constant<int, 4>{}); break;
+                case 16: blocks(std::integral_constant<int, 16>{}); break;
+                default: blocks(std::integral_constant<int, 20>{}); break;
+            }
+        } else if constexpr (EPI == 4) {                            // fp8 launches: {-, residual} x {-, GELU}, always de-quantising
+            switch (fmask & ~32) {
                 case 0: blocks(std::integral_constant<int, 0>{}); break;
                 case 4: blocks(std::integral_constant<int, 4>{}); break;
                 case 16: blocks(std::integral_constant<int, 16>{}); break;
@@ -241,7 +255,8 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                         const uint32_t oc = (uint32_t)(row * ldc + col);
                         const float v = element_rt(acc[i][j][r], bias ? bias[col] : 0.f, res ? res[(size_t)((uint32_t)(row * ldres + col))] : 0.f,
                                                 gate ? gate[(size_t)((uint32_t)(row * ldgate + col))] : 1.f, accum ? C[(size_t)oc] : 0.f, row, col);
-                        C[(size_t)oc] = v;                                  // (edge tiles keep the fp32 store whatever GF_NO_F32 says)
+                        C[(size_t)oc] = v;                                  // (edge tiles keep the fp32 store whatever GF_NO_F32 says; the fp8
+                                                                            // launcher sends e4m3-result launches with edge tiles elsewhere)
                         if (C16) C16[(size_t)oc] = m2f_bf16_bits(v);
                     }
                 }
@@ -580,6 +595,38 @@ __device__ __forceinline__ void ring_consumer(const GemmBatch& gb, char* smem, i
                 ring_lds_barrier();                                      // (#g) k-tile g has landed
                 const char* ab = smem + slot * C::SLOT + arow;
                 const char* bb = smem + slot * C::SLOT + brow;
+                if constexpr (EPI == 4) {
+                    // FP8 (OCP e4m3) operands: the producers moved the same 128-byte rows (the launcher hands over k and the leading
+                    // dimensions in byte PAIRS), a row now holds 128 k-values.  v_mfma_scale_f32_32x32x64_f8f6f4 (scale operands 0 =
+                    // unscaled; 2x the bf16 rate): lane (row l & 31, half l >> 5) supplies k = 64 s + 32 (l >> 5) + 0..31 of its row,
+                    // i.e. 16-byte chunks 4 s + 2 h and 4 s + 2 h + 1 of the swizzled image (tools/mfma_probe/f8f6f4_probe.hip).
+                    typedef int ring_v8i __attribute__((ext_vector_type(8)));
+                    const int h2 = (lane >> 5) * 2;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const int o0 = ((4 * st + h2) ^ x) << 4, o1 = ((4 * st + h2 + 1) ^ x) << 4;
+                        ring_v8i f8a[MI], f8b[NI];
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            const ring_u32x4 lo = *reinterpret_cast<const ring_u32x4*>(ab + i * 32 * C::ROW + o0);
+                            const ring_u32x4 hi = *reinterpret_cast<const ring_u32x4*>(ab + i * 32 * C::ROW + o1);
+                            f8a[i] = (ring_v8i){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                        }
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const ring_u32x4 lo = *reinterpret_cast<const ring_u32x4*>(bb + j * 32 * C::ROW + o0);
+                            const ring_u32x4 hi = *reinterpret_cast<const ring_u32x4*>(bb + j * 32 * C::ROW + o1);
+                            f8b[j] = (ring_v8i){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                        }
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f8b[j], f8a[i], acc[i][j], 0, 0, 0, 0, 0, 0);   // operands swapped, as below
+                    }
+                    slot = slot + 1 == S ? 0 : slot + 1;
+                    continue;
+                }
                 constexpr int KS = BK / 16;
                 bf16x8 fa[2][MI], fb[2][NI];
                 auto frags = [&](int ks, int buf) {

@@ -110,7 +110,8 @@ def test_gemm_large_m_tile_and_gelu_epilogue():
     _close(got32, 0.5 * pre32 * (1.0 + torch.erf(pre32 / 2.0 ** 0.5)), 1e-5, "fp32 GEMM + GELU")
 
 
-@pytest.mark.parametrize("shape", [(300, 200, 64), (1024, 768, 768), (4096 * 9 + 5, 1024 + 40, 256)])
+# (the last two take the ring form, gemm_ring_256x128_fp8.hip: edge tiles + a k remainder, and whole tiles incl. the e4m3 result)
+@pytest.mark.parametrize("shape", [(300, 200, 64), (1024, 768, 768), (4096 * 9 + 5, 1024 + 40, 256 + 48), (8192, 1024, 512)])
 def test_gemm_fp8_matches_dequantised_reference(shape):
     """fp8 (OCP e4m3) operands, fp32 accumulate: exact against an fp32 product of the SAME quantised values (the MFMA
     multiplies e4m3 x e4m3 exactly and accumulates in fp32), with the de-quantisation scale, bias, GELU and residual."""

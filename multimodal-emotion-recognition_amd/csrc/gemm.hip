@@ -1552,6 +1552,11 @@ hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStr
         if (vec_ok(p.a, a_rc, p.M)) p.flags |= GF_VEC_A;
         if (vec_ok(p.b, b_rc, p.N)) p.flags |= GF_VEC_B;
     }
+    {   // the classifier head's [T, n_classes] problems: FMA kernels over the whole chip instead of one column of MFMA tiles (skinny.hip)
+        const int sk = m2f_launch_gemm_skinny(gb, prec, layout, stream);
+        if (sk == 1) return hipSuccess;
+        if (sk < 0) return (hipError_t)(-sk);
+    }
     if (prec == M2F_PREC_BF16 && layout == M2F_LAYOUT_NN) {
         // dgrad against a weight whose TRANSPOSED bf16 shadow exists runs as the k-contiguous (forward) form, the
         // fastest staging path: C = A * B  ==  A * (B^T)^T

@@ -109,6 +109,7 @@ struct GemmBatch {
 #define M2F_SPLITK_MAX_TILES 512
 
 // RING form of the k-contiguous bf16 GEMM (gemm_ring.h): bm x bn = 128x128 or 128x64; the table form walks gb.table.
+int m2f_launch_gemm_skinny(const GemmBatch& gb, int prec, int layout, hipStream_t stream);      // skinny.hip: 1 launched, 0 not skinny, < 0 error
 bool m2f_gemm_stages_bf16(const GemmBatch& gb, int layout);      // host: does the bf16-mode launch read bf16 shadows only?
 bool m2f_gemm_ring_ok(const GemmBatch& gb);
 bool m2f_gemm_ring256_ok(const GemmBatch& gb);       // 256x128 tiles: bias / ReLU / GELU / residual epilogues only

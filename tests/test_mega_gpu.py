@@ -23,10 +23,10 @@ def _needs_the_mega_library():
     if "mega" not in os.path.basename(runtime.LIB_PATH) and "prof" not in os.path.basename(runtime.LIB_PATH):
         pytest.skip("persistent kernels are parked: build `make -C multimodal-emotion-recognition_amd/csrc mega` and run with "
                     "M2F_LIB=.../libm2fnet_hip_mega.so")
-    if os.environ.get("M2F_ATTN_BWD_OSLAB") != "1" or os.environ.get("M2F_ATTN_BF16") != "0":
-        pytest.skip("run with M2F_ATTN_BWD_OSLAB=1 M2F_ATTN_BF16=0: since round 3 the launch lists' attention kernels sum delta in "
-                    "another order (no O slab in LDS) and, in bf16 mode, stage from the bf16 shadows - the persistent kernels repeat "
-                    "the round-2 forms those switches bring back")
+    if os.environ.get("M2F_ATTN_BWD_OSLAB") != "1" or os.environ.get("M2F_ATTN_BF16") != "0" or os.environ.get("M2F_SKINNY") != "0":
+        pytest.skip("run with M2F_ATTN_BWD_OSLAB=1 M2F_ATTN_BF16=0 M2F_SKINNY=0: since round 3 the launch lists' attention kernels sum delta "
+                    "in another order (no O slab in LDS), stage from the bf16 shadows in bf16 mode, and the classifier's [T, n_classes] "
+                    "problems run as FMA kernels (skinny.hip) - the persistent kernels repeat the round-2 forms those switches bring back")
 
 
 def _model(cfg, sd, mega, precision="bf16"):

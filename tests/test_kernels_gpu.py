@@ -382,3 +382,23 @@ def test_attention_bf16_mode_forms(B, L, H, hd, ld, monkeypatch):
         scale = e[valid].abs().max().item()
         assert (a - b)[valid].abs().max().item() <= 2e-2 * scale
         assert (a - e)[valid].abs().max().item() <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("prec", [runtime.F32, runtime.BF16])
+@pytest.mark.parametrize("src16", [False, True])
+def test_skinny_classifier_gemms(prec, src16):
+    """csrc/skinny.hip behind m2f_gemm: [T, K] x [7, K]^T + bias (the logits) and [T, 7] x [7, N] with the ReLU / dropout gate
+    (their input gradient), vectorised and element-wise paths, fp32 and bf16 (from fp32 sources or from bf16 shadows)."""
+    if src16 and prec != runtime.BF16:
+        pytest.skip("shadows are a bf16-mode thing")
+    r = (lambda t: t.to(torch.bfloat16).double()) if prec == runtime.BF16 else (lambda t: t.double())
+    for (T, K, ncls) in [(300, 768, 7), (37, 50, 3), (1024, 1024, 8)]:
+        h, w, bias = _rand(T, K, seed=61), _rand(ncls, K, seed=62) * 0.1, _rand(ncls, seed=63)
+        got = F.gemm(h, w, F.NT, prec, bias=bias, src16=src16)
+        _close(got.double(), r(h) @ r(w).t() + bias.double(), 2e-5, f"skinny NT {T}x{ncls}x{K}")       # (the reference rounds the operands as the kernel does)
+        dl, gate = _rand(T, ncls, seed=64), _rand(T, K, seed=65)
+        got = F.gemm(dl, w, F.NN, prec, gate=gate, gate_scale=1.25, src16=src16)
+        ref = (r(dl) @ r(w)) * (gate.double() > 0) * 1.25
+        _close(got.double(), ref, 2e-5, f"skinny NN {T}x{K}x{ncls}")
+        # the same arithmetic per row whatever the number of rows (packed and padded plans must agree bit for bit)
+        assert torch.equal(F.gemm(h[:5].contiguous(), w, F.NT, prec, bias=bias, src16=src16), F.gemm(h, w, F.NT, prec, bias=bias, src16=src16)[:5])

@@ -181,6 +181,13 @@ int m2f_adam_step_g16(float* params, const uint16_t* grads_bf16, float* exp_avg,
 int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                            uint16_t* param_shadow, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                            const float* grad_scale_ptr, m2f_stream_t stream);
+/* ... over the parameter tensors at flat offsets [first, end) only (both the offset of a tensor; end < 0: to the last one), reading the
+ * gradients as fp32 or (grads_bf16 != 0) as bf16 with the same indexing.  This is what lets the data-parallel path - which steps
+ * bucket by bucket behind each bucket's all-reduce, on the reduced bf16 buffer when the exchange is bf16 - keep the parameter
+ * shadows current as well (dp.GradReducer aligns its buckets to tensor boundaries; optim.FusedAdam.step_ranges). */
+int m2f_adam_step_shadowed_range(const m2f_config* cfg, float* params, const void* grads, int grads_bf16, float* exp_avg,
+                                 float* exp_avg_sq, uint16_t* param_shadow, int64_t first, int64_t end, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int step, const float* grad_scale_ptr, m2f_stream_t stream);
 
 /* bf16-mode plans write every activation twice - fp32 and the bf16 shadow the GEMMs / attention kernels stage from.  When a plan
  * is built, the readers of every workspace buffer are enumerated from its final launch lists; a copy nobody reads is not written

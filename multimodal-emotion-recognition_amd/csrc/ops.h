@@ -299,9 +299,10 @@ hipError_t m2f_launch_adam(float* p, const void* g, int g_is_bf16, float* m, flo
 // of 4096 elements).
 struct AdamItem { long long off, soff, soff_t; int rows, cols, tile_begin, tiles_c; };
 #define M2F_ADAM_MAX_ITEMS 1024
-hipError_t m2f_launch_adam_shadowed(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items,
-                                    const int* tile_begin, int n_items, int total_tiles, float lr, float beta1, float beta2,
-                                    float eps, float weight_decay, int step, const float* grad_scale_ptr, hipStream_t stream);
+hipError_t m2f_launch_adam_shadowed(float* p, const void* g, int g_is_bf16, float* m, float* v, uint16_t* shadow, const AdamItem* items,
+                                    const int* tile_begin, int n_items, int tile_first, int total_tiles, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
+                                    hipStream_t stream);
 
 #ifdef __HIPCC__
 // shadow address of a workspace element, or null (no shadows / pointer outside the workspace, e.g. the gradient buffer)

@@ -1859,9 +1859,9 @@ int m2f_param_shadow_init(const m2f_config* cfg, uint16_t* param_shadow, m2f_str
     return 0;
 }
 
-int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                           uint16_t* param_shadow, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                           const float* grad_scale_ptr, m2f_stream_t stream) {
+int m2f_adam_step_shadowed_range(const m2f_config* cfg, float* params, const void* grads, int grads_bf16, float* exp_avg,
+                                 float* exp_avg_sq, uint16_t* param_shadow, int64_t first, int64_t end, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int step, const float* grad_scale_ptr, m2f_stream_t stream) {
     thread_local m2f_config cached_cfg;
     thread_local AdamTable cached;
     thread_local bool have = false;
@@ -1870,13 +1870,30 @@ int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* gr
         if (adam_table(*cfg, t)) return 1;
         cached = t; cached_cfg = *cfg; have = true;
     }
+    // parameters [first, end) of the flat buffers = a run of whole table items (end < 0, or past the last tensor: to the end)
+    const int n = (int)cached.items.size();
+    int i0 = 0, i1 = n;
+    while (i0 < n && cached.items[i0].off < first) ++i0;
+    if (end >= 0) { i1 = i0; while (i1 < n && cached.items[i1].off < end) ++i1; }
+    if (i0 >= n || cached.items[i0].off != first || i1 <= i0)
+        return fail("m2f_adam_step_shadowed_range: [first, end) must start at a parameter tensor and hold at least one");
+    if (end >= 0 && i1 < n && cached.items[i1].off != end)
+        return fail("m2f_adam_step_shadowed_range: `end` must be the offset of a parameter tensor (or < 0)");
     const size_t sh = (cached.shadow_elems + 127) / 128 * 128;
     const char* tab = reinterpret_cast<const char*>(param_shadow + sh);
-    M2F_HIP(m2f_launch_adam_shadowed(params, grads, exp_avg, exp_avg_sq, param_shadow, reinterpret_cast<const AdamItem*>(tab),
-                                     reinterpret_cast<const int*>(tab + cached.items.size() * sizeof(AdamItem)), (int)cached.items.size(),
-                                     cached.total_tiles, lr, beta1, beta2, eps, weight_decay, step, grad_scale_ptr,
-                                     static_cast<hipStream_t>(stream)));
+    const AdamItem* items = reinterpret_cast<const AdamItem*>(tab);
+    const int* tile_begin = reinterpret_cast<const int*>(tab + cached.items.size() * sizeof(AdamItem));
+    M2F_HIP(m2f_launch_adam_shadowed(params, grads, grads_bf16, exp_avg, exp_avg_sq, param_shadow, items + i0, tile_begin + i0, i1 - i0,
+                                     cached.tile_begin[i0], cached.tile_begin[i1], lr, beta1, beta2, eps, weight_decay, step,
+                                     grad_scale_ptr, static_cast<hipStream_t>(stream)));
     return 0;
+}
+
+int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                           uint16_t* param_shadow, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           const float* grad_scale_ptr, m2f_stream_t stream) {
+    return m2f_adam_step_shadowed_range(cfg, params, grads, 0, exp_avg, exp_avg_sq, param_shadow, 0, -1, lr, beta1, beta2, eps,
+                                        weight_decay, step, grad_scale_ptr, stream);
 }
 
 int m2f_plan_skipped_copies(m2f_plan* plan) { return plan ? plan->n_no_f32 : -1; }

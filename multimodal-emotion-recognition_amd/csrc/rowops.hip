@@ -397,12 +397,27 @@ __global__ void m2f_rng_advance_kernel(uint32_t* rng) {
     }
 }
 
+// Adam update of four consecutive elements (registers in, registers out).  Every optimizer kernel of this file goes through this
+// one function and its contractions are spelled out (the file is compiled with fp contraction off): left to the compiler
+// (contract(fast)) the flat kernel and the shadow-writing kernel fused `g * gs + wd * p` differently once one of them became a
+// template, and a data-parallel run (bucket-wise shadow-writing steps) drifted from the single-process run by an ulp per step.
+__device__ __forceinline__ void adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float gs, float lr_bc1, float beta1,
+                                      float beta2, float eps, float wd, float inv_sqrt_bc2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gr = __builtin_fmaf(gg[e], gs, wd * pp[e]);     // coupled L2 (Adam, not AdamW)
+        mm[e] = __builtin_fmaf(beta1, mm[e], (1.f - beta1) * gr);
+        vv[e] = __builtin_fmaf(beta2, vv[e], ((1.f - beta2) * gr) * gr);
+        const float denom = __builtin_fmaf(sqrtf(vv[e]), inv_sqrt_bc2, eps);
+        pp[e] = __builtin_fmaf(-lr_bc1, mm[e] / denom, pp[e]);
+    }
+}
+
 // G16: the gradient buffer holds bf16 (the data-parallel bf16 exchange), everything else stays fp32
 template <bool G16>
 __global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, int64_t n4, float lr_bc1, float beta1, float beta2,
                                                        float eps, float wd, float inv_sqrt_bc2, const float* __restrict__ gs_ptr) {
-#pragma clang fp contract(fast)      // (this kernel has no twin in mega.hip to stay bit-identical with)
     // g, m, v are streamed once per step: nontemporal accesses keep them from displacing p (re-read by the bf16 cast that
     // opens the next forward) in the L2 / Infinity Cache; measured 0.554 -> 0.524 ms per C3 step for the optimizer part
     const float gs = gs_ptr ? 1.0f / *gs_ptr : 1.0f;
@@ -418,47 +433,46 @@ __global__ __launch_bounds__(256) void m2f_adam_kernel(float* __restrict__ p, co
         }
         f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
         f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gr = gg[e] * gs + wd * pp[e];                  // coupled L2 (Adam, not AdamW)
-            mm[e] = beta1 * mm[e] + (1.f - beta1) * gr;
-            vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
-            const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
-            pp[e] -= lr_bc1 * (mm[e] / denom);
-        }
+        adam4(pp, gg, mm, vv, gs, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2);
         reinterpret_cast<f32x4*>(p)[i] = pp;
         __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m) + i);
         __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
     }
 }
 
-// Adam update of four consecutive elements (registers in, registers out) - the arithmetic of m2f_adam_kernel
-__device__ __forceinline__ void adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float gs, float lr_bc1, float beta1,
-                                      float beta2, float eps, float wd, float inv_sqrt_bc2) {
-#pragma clang fp contract(fast)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float gr = gg[e] * gs + wd * pp[e];                  // coupled L2 (Adam, not AdamW)
-        mm[e] = beta1 * mm[e] + (1.f - beta1) * gr;
-        vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
-        const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
-        pp[e] -= lr_bc1 * (mm[e] / denom);
+// four consecutive gradient elements from the fp32 buffer or (G16: the data-parallel bf16 exchange) from the reduced bf16 buffer
+template <bool G16>
+__device__ __forceinline__ f32x4 adam_grad4(const void* g, long long o) {
+    if constexpr (G16) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(g) + o);
+        return (f32x4){__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
+                       __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
+    } else {
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(static_cast<const float*>(g) + o));
     }
 }
+template <bool G16>
+__device__ __forceinline__ float adam_grad1(const void* g, long long o) {
+    if constexpr (G16) return __builtin_bit_cast(float, (uint32_t)static_cast<const uint16_t*>(g)[o] << 16);
+    else return static_cast<const float*>(g)[o];
+}
 
-// see ops.h (AdamItem).  Persistent 1-D grid over the tile list; tile -> item by bisection of the prefix array (kept in LDS).
-__global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// see ops.h (AdamItem).  Persistent 1-D grid over tiles [tile_first, total_tiles) of items[0, n_items) (tile_begin[] holds absolute
+// tile numbers); tile -> item by bisection of the prefix array (kept in LDS).
+template <bool G16>
+__global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                                               float* __restrict__ v, uint16_t* __restrict__ sh,
                                                               const AdamItem* __restrict__ items, const int* __restrict__ tile_begin,
-                                                              int n_items, int total_tiles, float lr_bc1, float beta1, float beta2,
-                                                              float eps, float wd, float inv_sqrt_bc2, const float* __restrict__ gs_ptr) {
+                                                              int n_items, int tile_first, int total_tiles, float lr_bc1, float beta1,
+                                                              float beta2, float eps, float wd, float inv_sqrt_bc2,
+                                                              const float* __restrict__ gs_ptr) {
     __shared__ float tile[64][65];
     __shared__ int tb[M2F_ADAM_MAX_ITEMS + 1];
     const int tid = threadIdx.x;
     for (int i = tid; i <= n_items; i += 256) tb[i] = tile_begin[i];
     __syncthreads();
     const float gs = gs_ptr ? 1.0f / *gs_ptr : 1.0f;
-    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    for (int t = tile_first + (int)blockIdx.x; t < total_tiles; t += gridDim.x) {
         int lo = 0, hi = n_items - 1;                               // last item whose first tile is <= t (block-uniform)
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict_
                 if (idx < it.cols) {
                     const long long o = it.off + idx;
                     f32x4 pp = *reinterpret_cast<const f32x4*>(p + o);
-                    const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o));
+                    const f32x4 gg = adam_grad4<G16>(g, o);
                     f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + o));
                     f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + o));
                     adam4(pp, gg, mm, vv, gs, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2);
@@ -497,14 +511,14 @@ __global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict_
             const long long o = it.off + (long long)(in[i] ? gr : 0) * cols + (in[i] ? gc : 0);
             if (vec) {
                 pp[i] = *reinterpret_cast<const f32x4*>(p + o);
-                gg[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o));
+                gg[i] = adam_grad4<G16>(g, o);
                 mm[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + o));
                 vv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + o));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const long long oe = o + ((in[i] && gc + e < cols) ? e : 0);
-                    pp[i][e] = p[oe]; gg[i][e] = g[oe]; mm[i][e] = m[oe]; vv[i][e] = v[oe];
+                    pp[i][e] = p[oe]; gg[i][e] = adam_grad1<G16>(g, oe); mm[i][e] = m[oe]; vv[i][e] = v[oe];
                 }
             }
         }
@@ -881,14 +895,20 @@ hipError_t m2f_launch_rng_advance(uint32_t* rng, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t m2f_launch_adam_shadowed(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items,
-                                    const int* tile_begin, int n_items, int total_tiles, float lr, float beta1, float beta2,
-                                    float eps, float weight_decay, int step, const float* grad_scale_ptr, hipStream_t stream) {
-    if (n_items < 1 || n_items > M2F_ADAM_MAX_ITEMS || total_tiles < 1 || !items || !tile_begin || !shadow) return hipErrorInvalidValue;
+hipError_t m2f_launch_adam_shadowed(float* p, const void* g, int g_is_bf16, float* m, float* v, uint16_t* shadow, const AdamItem* items,
+                                    const int* tile_begin, int n_items, int tile_first, int total_tiles, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
+                                    hipStream_t stream) {
+    const int n_tiles = total_tiles - tile_first;
+    if (n_items < 1 || n_items > M2F_ADAM_MAX_ITEMS || tile_first < 0 || n_tiles < 1 || !items || !tile_begin || !shadow) return hipErrorInvalidValue;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const int blocks = total_tiles < 256 * 8 ? total_tiles : 256 * 8;
-    hipLaunchKernelGGL(m2f_adam_shadow_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, shadow, items, tile_begin, n_items,
-                       total_tiles, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
+    const int blocks = n_tiles < 256 * 8 ? n_tiles : 256 * 8;
+    if (g_is_bf16)
+        hipLaunchKernelGGL(m2f_adam_shadow_kernel<true>, dim3(blocks), dim3(256), 0, stream, p, g, m, v, shadow, items, tile_begin, n_items,
+                           tile_first, total_tiles, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
+    else
+        hipLaunchKernelGGL(m2f_adam_shadow_kernel<false>, dim3(blocks), dim3(256), 0, stream, p, g, m, v, shadow, items, tile_begin, n_items,
+                           tile_first, total_tiles, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
     return hipGetLastError();
 }
 

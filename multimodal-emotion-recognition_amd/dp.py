@@ -152,6 +152,29 @@ class GradReducer:
                 self.exchange = exchange = "fp32"
         self.buf16 = torch.empty(n_params, dtype=torch.bfloat16, device=buf.device) if exchange == "bf16" else None
         self._work = []
+        self._starts = None
+
+    def align_to(self, tensor_starts) -> None:
+        """Move the bucket edges to the nearest parameter-tensor boundaries (offsets into the flat buffer): the fused optimizer can
+        then step a bucket with its shadow-writing kernel (optim.FusedAdam.step_ranges), which works on whole tensors."""
+        starts = sorted(set(int(o) for o in tensor_starts))
+        if not starts or starts[0] != 0:
+            return
+        self._starts = starts
+
+        def snap_all(chunks, last):
+            edges = sorted(set([0] + [self._snap(a) for a, _ in chunks[1:]] + [last]))
+            return [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+        self.chunks = snap_all(self.chunks, self.buf.numel())
+        self.param_chunks = snap_all(self.param_chunks, self.n)
+
+    def _snap(self, x: int) -> int:
+        if not self._starts:
+            return x
+        import bisect
+        i = bisect.bisect_left(self._starts, x)
+        cands = [self._starts[j] for j in (i - 1, i) if 0 <= j < len(self._starts)]
+        return min(cands, key=lambda c: abs(c - x))
 
     @property
     def tail(self) -> torch.Tensor:
@@ -220,7 +243,7 @@ class GradReducer:
             return
         split = max(0, min(int(split) // 64 * 64, self.n))
         n_b = max(1, len(self.chunks) - 1)
-        edges = [round(i * split / n_b / 64) * 64 for i in range(n_b)] + [split]
+        edges = sorted(set([self._snap(round(i * split / n_b / 64) * 64) for i in range(n_b)] + [split]))
         head = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]            # encoder part of the parameters, in buckets
         if self.exchange == "bf16":
             tail = self.buf[self.n:]
@@ -297,6 +320,7 @@ class DataParallelStep:
         eng = model.engine()
         eng.ensure_grad()
         self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets, exchange)
+        self.reducer.align_to(o for (_, o, _, _) in eng.items)      # buckets of whole tensors: the optimizer keeps the bf16 parameter shadows current
         optimizer.grad_scale = self.reducer.global_den
 
     def __call__(self, text, audio, mask, emotion, label_smoothing: float = 0.1, class_weights=None,

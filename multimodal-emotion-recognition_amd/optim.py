@@ -124,20 +124,45 @@ class FusedAdam(torch.optim.Optimizer):
         flat buffers (hi clipped to the parameter count; lo, hi multiples of 4).  `before_each(i)` runs before range i
         is launched - the data-parallel path waits there for that range's all-reduce, so the update of one bucket
         overlaps the exchange of the next.  `grads`: gradient buffer to read instead of the engine's (same indexing;
-        fp32 or bf16 - the reduced buffer of the bf16 exchange)."""
+        fp32 or bf16 - the reduced buffer of the bf16 exchange).  Ranges made of whole parameter tensors keep the bf16
+        parameter shadows current (m2f_adam_step_shadowed_range); other ranges leave them to the next forward's casts."""
         eng = self._bind()
         g = self.param_groups[0]
         flat_grad = eng.ensure_grad() if grads is None else grads
         n = eng.flat.numel()
         self._step += 1
-        eng.invalidate_shadows()              # this path updates the parameters only: the next forward re-casts their bf16 shadows
+        ranges = [(lo, min(hi, n)) for (lo, hi) in ranges]
+        # bf16 mode with the model-wide parameter shadows: ranges that start and end at parameter tensors (dp.GradReducer aligns its
+        # buckets that way) go through the shadow-writing kernel, so the next forward needs no parameter casts under data parallelism
+        # either; anything else updates the parameters only and the next forward re-casts
+        starts = self._tensor_starts(eng)
+        shadowed = eng.wshadow is not None and all(lo in starts and (hi >= n or hi in starts) for lo, hi in ranges if hi > lo)
+        if not shadowed:
+            eng.invalidate_shadows()
         for i, (lo, hi) in enumerate(ranges):
             if before_each is not None:
                 before_each(i)
-            hi = min(hi, n)
-            if hi > lo:
+            if hi <= lo:
+                continue
+            if shadowed:
+                runtime.adam_step_shadowed(eng.cfg, eng.flat, flat_grad, self._m, self._v, eng.wshadow, self._step, g["lr"], g["betas"],
+                                           g["eps"], g["weight_decay"], self.grad_scale, first=lo, end=(-1 if hi >= n else hi))
+            else:
                 runtime.adam_step(eng.flat[lo:hi], flat_grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step, g["lr"],
                                   g["betas"], g["eps"], g["weight_decay"], self.grad_scale)
+        if shadowed:
+            covered = sorted((lo, hi) for lo, hi in ranges if hi > lo)
+            whole = bool(covered) and covered[0][0] == 0 and covered[-1][1] >= n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            if whole:
+                eng.mark_shadows_fresh()
+            else:
+                eng.invalidate_shadows()
+
+    def _tensor_starts(self, eng):
+        if getattr(self, "_starts_of", None) is not eng:
+            self._starts = frozenset(int(o) for (_, o, _, _) in eng.items)
+            self._starts_of = eng
+        return self._starts
 
     def state_dict(self):
         if self._engine is not None and self._step > 0:

@@ -69,6 +69,8 @@ SIGNATURES = {
     "m2f_plan_params_fresh": (c_int, [c_void_p, c_int]),
     "m2f_adam_step_shadowed": (c_int, [ctypes.POINTER(M2FConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                        c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "m2f_adam_step_shadowed_range": (c_int, [ctypes.POINTER(M2FConfigC), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                             c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "m2f_plan_skipped_copies": (c_int, [c_void_p]),
     "m2f_plan_destroy": (None, [c_void_p]),
     "m2f_plan_buffer": (c_void_p, [c_void_p, c_int]),
@@ -510,12 +512,15 @@ def param_shadow_buffer(cfg: M2FConfig, device) -> torch.Tensor:
 
 def adam_step_shadowed(cfg: M2FConfig, params, grads, exp_avg, exp_avg_sq, param_shadow, step: int, lr: float,
                        betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                       grad_scale: Optional[torch.Tensor] = None) -> None:
-    """torch.optim.Adam's update over the whole flat buffers + the bf16 shadows of every 2-D parameter (m2f_adam_step_shadowed)."""
+                       grad_scale: Optional[torch.Tensor] = None, first: int = 0, end: int = -1) -> None:
+    """torch.optim.Adam's update over the flat buffers + the bf16 shadows of every 2-D parameter (m2f_adam_step_shadowed_range).
+    The buffers are always passed WHOLE; `[first, end)` - offsets of parameter tensors, end < 0: to the last one - selects what is
+    updated; `grads` fp32, or bf16 (the reduced buffer of the data-parallel bf16 exchange, same indexing)."""
     cc = config_to_c(cfg)
-    check(lib().m2f_adam_step_shadowed(ctypes.byref(cc), params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(),
-                                       exp_avg_sq.data_ptr(), param_shadow.data_ptr(), lr, betas[0], betas[1], eps,
-                                       weight_decay, step, ptr(grad_scale), stream_ptr()), "m2f_adam_step_shadowed")
+    check(lib().m2f_adam_step_shadowed_range(ctypes.byref(cc), params.data_ptr(), grads.data_ptr(), int(grads.dtype == torch.bfloat16),
+                                             exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param_shadow.data_ptr(), int(first), int(end),
+                                             lr, betas[0], betas[1], eps, weight_decay, step, ptr(grad_scale), stream_ptr()),
+          "m2f_adam_step_shadowed_range")
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,

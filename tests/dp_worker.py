@@ -134,7 +134,22 @@ def main():
             torch.cuda.synchronize()
             plan = next(iter(mb.engine().plans.values()))
             res["D"][(overlap, exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(),
-                                             "split": plan.split_offset(), "exchange": sb.reducer.exchange}
+                                             "split": plan.split_offset(), "exchange": sb.reducer.exchange,
+                                             "fresh": mb.engine().shadows_fresh()}
+    # ... and the same steps with per-plan shadows re-cast at every forward (round-2 behaviour): the bucket-wise shadow-writing
+    # optimizer must leave the same parameters
+    os.environ["M2F_SHARED_SHADOWS"] = "0"
+    for exchange in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        mb = M2FNet(cfg, precision="bf16").to(device).train()
+        mb.load_state_dict({k: v.to(device) for k, v in synth.make_state_dict(cfg).items()})
+        ob = FusedAdam(mb, lr=1e-3, weight_decay=0.01)
+        sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange=exchange, overlap=True)
+        losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(4)]
+        torch.cuda.synchronize()
+        res["D"][("recast", exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(),
+                                          "fresh": mb.engine().shadows_fresh()}
+    os.environ.pop("M2F_SHARED_SHADOWS", None)
 
     # ---- C: the training loop of src/train.py under two ranks -----------------------------------------------------
     cfg_loop = loop_config(os.path.join(out_dir, "loop_dp"))

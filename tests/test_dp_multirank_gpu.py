@@ -93,3 +93,8 @@ def test_overlapped_exchange_equals_exchange_after_backward(dp2_results):
         assert torch.equal(a["params"], b["params"])
         assert torch.equal(a["params"], r1["D"][(True, exchange)]["params"])
         assert a["losses"][-1] < a["losses"][0]
+        # the optimizer stepped bucket by bucket through its shadow-writing kernel (buckets = whole tensors): the bf16 parameter shadows
+        # are current, the next forward casts nothing - and the parameters are those of the path that re-casts at every forward
+        c = r0["D"][("recast", exchange)]
+        assert a["fresh"] and b["fresh"] and not c["fresh"]
+        assert a["losses"] == c["losses"] and torch.equal(a["params"], c["params"])

@@ -416,6 +416,8 @@ def test_step_in_two_parts_equals_the_whole_step(golden_dir, name, use_graph):
     captured graphs), and after part 0 ALONE the gradient buffer is already final from m2f_plan_split_offset on - the fusion
     stack's and the classifier's parameters, i.e. the bucket that travels while part 1 runs."""
     from mer_amd import layout
+    if os.environ.get("M2F_PACKED") == "1":
+        pytest.skip("builds its padded plan by hand (eng.plan without a valid-row count) and compares it with train_step's plan")
     fx = _load(golden_dir, name)
     cfg, text, audio, key_pad, emotion = _inputs(name, fx)
     cfg = dict(cfg, dropout=0.3)

@@ -150,7 +150,8 @@ def test_plan_cache_is_bounded_over_real_dialogue_lengths():
             assert (eng.flat_grad - eng_x.flat_grad).abs().max().item() <= 1e-6 * eng_x.flat_grad.abs().max().item()
     eng = m.engine()
     shapes = sorted({(k[0], k[1]) for k in eng.plans})
-    assert len(eng.plans) <= 6 and {s[1] for s in shapes} <= {16, 32, 48}, shapes
+    # (forced packing - M2F_PACKED=1 - adds the token-row bucket to the plan key: more plans of the same (B, L) buckets)
+    assert len(eng.plans) <= (6 if os.environ.get("M2F_PACKED") != "1" else 16) and {s[1] for s in shapes} <= {16, 32, 48}, shapes
     assert len({s[1] for s in shapes}) <= 3
     assert eng.plan_bytes() <= eng.max_plans * max(p.nbytes() for p in eng.plans.values())
     # LRU: with room for two plans only, the oldest goes

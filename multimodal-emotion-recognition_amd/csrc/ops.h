@@ -278,6 +278,9 @@ hipError_t m2f_launch_embed_ln(const int64_t* ids, const int64_t* pos_ids, const
 hipError_t m2f_launch_quant_fp8(const float* src, uint8_t* dst, int64_t n, float scale, hipStream_t stream);
 
 // in-place: x[t, c] *= keep(site, t*d + c) / (1 - p)
+// (x2 != null: a second buffer of the same shape with its own site, same launch)
+hipError_t m2f_launch_dropout_inplace2(float* x, float* x2, int T, int d, int ld, uint32_t site, uint32_t site2, const uint32_t* rng,
+                                       uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream);
 hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
                                       uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream);
 // rng.step += 1 (device side, graph-replay safe)

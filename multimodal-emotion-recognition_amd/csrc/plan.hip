@@ -185,6 +185,7 @@ struct Launch {
     AttnBatch ab;
     LnBatch lb;
     float* dptr = nullptr; int dT = 0, dd = 0, dld = 0; uint32_t dsite = 0;
+    float* dptr2 = nullptr; uint32_t dsite2 = 0;      // OP_DROPOUT: a second buffer of the same shape in the same launch
     std::vector<std::pair<int, int>> src;
     int group = 0;
 };
@@ -826,6 +827,12 @@ void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Laun
                 break;
             case OP_DROPOUT:
                 l.dptr = o.dptr; l.dT = o.dT; l.dd = o.dd; l.dld = o.dld; l.dsite = o.dsite;
+                // two in-place dropouts in a row over buffers of one shape (the modalities' post-projection gradients): one launch
+                if (!out.empty() && out.back().kind == OP_DROPOUT && !out.back().dptr2 && out.back().group == l.group &&
+                    out.back().dT == l.dT && out.back().dd == l.dd && out.back().dld == l.dld && out.back().dptr != l.dptr) {
+                    out.back().dptr2 = l.dptr; out.back().dsite2 = l.dsite;
+                    continue;
+                }
                 break;
         }
         out.push_back(l);
@@ -943,10 +950,12 @@ void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first,
                 break;
             }
             case OP_DROPOUT: {
-                MegaDrop d; d.x = l.dptr; d.T = l.dT; d.d = l.dd; d.ld = l.dld; d.site = l.dsite;
-                const int prob = (int)mt.drop.size();
-                mt.drop.push_back(d);
-                for (int r0 = 0; r0 < l.dT; r0 += 16) push(MK_DROPOUT, prob, r0, std::min(16, l.dT - r0), r0, r0 + 15, -1);
+                for (int which = 0; which < (l.dptr2 ? 2 : 1); ++which) {
+                    MegaDrop d; d.x = which ? l.dptr2 : l.dptr; d.T = l.dT; d.d = l.dd; d.ld = l.dld; d.site = which ? l.dsite2 : l.dsite;
+                    const int prob = (int)mt.drop.size();
+                    mt.drop.push_back(d);
+                    for (int r0 = 0; r0 < l.dT; r0 += 16) push(MK_DROPOUT, prob, r0, std::min(16, l.dT - r0), r0, r0 + 15, -1);
+                }
                 break;
             }
         }
@@ -1151,7 +1160,7 @@ int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, const std:
                         if (l.kind == OP_LN_BWD) { mark(q.dy, T, ld, (size_t)q.d); mark(q.extra, T, ld, (size_t)q.d); }
                     }
                     break;
-                case OP_DROPOUT: mark(l.dptr, (size_t)l.dT, (size_t)l.dld, (size_t)l.dd); break;
+                case OP_DROPOUT: mark(l.dptr, (size_t)l.dT, (size_t)l.dld, (size_t)l.dd); mark(l.dptr2, (size_t)l.dT, (size_t)l.dld, (size_t)l.dd); break;
                 default: break;
             }
         }
@@ -1589,7 +1598,7 @@ int run_launches(m2f_plan& P, std::vector<Launch>& ls, hipStream_t s, size_t fir
             case OP_ATTN_BWD: e = m2f_launch_attn_bwd(l.ab, s); break;
             case OP_LN_FWD: e = m2f_launch_ln_fwd(l.lb, s); break;
             case OP_LN_BWD: e = m2f_launch_ln_bwd(l.lb, s); break;
-            case OP_DROPOUT: e = m2f_launch_dropout_inplace(l.dptr, l.dT, l.dd, l.dld, l.dsite, P.rng, P.drop_thresh, P.drop_scale, P.sh, s); break;
+            case OP_DROPOUT: e = m2f_launch_dropout_inplace2(l.dptr, l.dptr2, l.dT, l.dd, l.dld, l.dsite, l.dsite2, P.rng, P.drop_thresh, P.drop_scale, P.sh, s); break;
         }
         if (g_prof) g_prof->end();
         if (e != hipSuccess) return hipfail(e, "kernel launch");

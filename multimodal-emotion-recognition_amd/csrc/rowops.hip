@@ -319,10 +319,12 @@ __global__ __launch_bounds__(256) void m2f_loss_finalize_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void m2f_dropout_inplace_kernel(float* __restrict__ x, int T, int d, int ld, uint32_t site,
-                                                                  const uint32_t* __restrict__ rng, uint32_t thresh, float scale,
-                                                                  ShadowMap sh) {
-    const uint32_t key = m2f_site_key(rng, site);
+// (blockIdx.y = 1: the second buffer of the launch - the two modalities' post-projection gradients share one launch)
+__global__ __launch_bounds__(256) void m2f_dropout_inplace_kernel(float* __restrict__ x0, float* __restrict__ x1, int T, int d, int ld,
+                                                                  uint32_t site0, uint32_t site1, const uint32_t* __restrict__ rng,
+                                                                  uint32_t thresh, float scale, ShadowMap sh) {
+    float* __restrict__ x = blockIdx.y ? x1 : x0;
+    const uint32_t key = m2f_site_key(rng, blockIdx.y ? site1 : site0);
     const size_t n = (size_t)T * d;
     uint16_t* x16 = m2f_shadow_of(sh, x);
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
@@ -625,13 +627,18 @@ hipError_t m2f_launch_loss_finalize(const float* loss_terms, int T, int C, float
     return hipGetLastError();
 }
 
-hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
-                                      uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream) {
+hipError_t m2f_launch_dropout_inplace2(float* x, float* x2, int T, int d, int ld, uint32_t site, uint32_t site2, const uint32_t* rng,
+                                       uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream) {
     const size_t n = (size_t)T * d;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(m2f_dropout_inplace_kernel, dim3(blocks), dim3(256), 0, stream, x, T, d, ld, site, rng, thresh, scale, sh);
+    hipLaunchKernelGGL(m2f_dropout_inplace_kernel, dim3(blocks, x2 ? 2 : 1), dim3(256), 0, stream, x, x2, T, d, ld, site, site2, rng, thresh,
+                       scale, sh);
     return hipGetLastError();
+}
+hipError_t m2f_launch_dropout_inplace(float* x, int T, int d, int ld, uint32_t site, const uint32_t* rng,
+                                      uint32_t thresh, float scale, ShadowMap sh, hipStream_t stream) {
+    return m2f_launch_dropout_inplace2(x, nullptr, T, d, ld, site, 0u, rng, thresh, scale, sh, stream);
 }
 
 // ---- 64x64 transposing tile: src fp32 [rows][ld] -> bf16 dst [rows][ldd] (optional) and bf16 dst_t [cols][ldt] ------------

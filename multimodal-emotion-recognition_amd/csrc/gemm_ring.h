@@ -351,6 +351,9 @@ __device__ __forceinline__ void ring_producer(const GemmBatch& gb, char* smem, i
     constexpr int BK = C::BK;
     typedef __attribute__((address_space(3))) void lds_void;
     // ================================ PRODUCER: global -> LDS ring (no registers) ================================
+    // the k-loops are bound by how fast the LDS-DMA instructions get issued: the producer waves go ahead of the MFMA waves at the
+    // SIMDs' issue arbiters (levels 1 / 2 / 3 alike: C3 fwd+bwd -11 .. -18 us in two same-box A/Bs, profiles/r03_dev_producer_priority_ab.txt)
+    __builtin_amdgcn_s_setprio(2);
     auto rsrc_of = [](const uint16_t* q, int rows, int ld) {
         const unsigned long long u = reinterpret_cast<unsigned long long>(q);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));

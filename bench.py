@@ -151,12 +151,12 @@ PARTS = ["encoders", "fusion", "classifier"]
 
 
 def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump="", packed=False,
-                 repeats=1, overlap=True):
+                 repeats=1, overlap=False, algorithm="all_reduce"):
     cfg, B, L = wl["cfg"], wl["B"], wl["L"]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=dtype, shape_buckets=False).to(device).train()      # the plan IS the workload's (B, L): no bucket padding
     opt = FusedAdam(model, lr=5e-5, weight_decay=0.01)
-    stepper = dp.DataParallelStep(model, opt, n_buckets=buckets, exchange=exchange)
+    stepper = dp.DataParallelStep(model, opt, n_buckets=buckets, exchange=exchange, overlap=overlap, algorithm=algorithm)
     text, audio, mask, emotion = synthetic_batch(cfg, B, L, rank, device, ragged=ragged)
     n_valid = int((~mask).sum().item())                # utterances of this rank's batch (= B*L unless --ragged)
     eng = model.engine()
@@ -216,6 +216,38 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                 torch.distributed.barrier()
             rep_ms.append(dp.reduce_metrics([time.perf_counter() - tr0], device=device)[0] / steps * 1e3)
 
+        # ---- N > 1: what the exchange costs, so that a scaling record explains itself ---------------------------------------------
+        comm = None
+        if world > 1:
+            red = stepper.reducer
+            n_c = max(5, min(steps, 20))
+
+            def bracket(fn, n):
+                torch.distributed.barrier()
+                torch.cuda.synchronize()
+                tc0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                side.synchronize()
+                torch.cuda.synchronize()
+                torch.distributed.barrier()
+                return dp.reduce_metrics([time.perf_counter() - tc0], device=device)[0] / n * 1e3
+            for _ in range(3):
+                red.exchange_only()
+            alone_ms = bracket(red.exchange_only, n_c)          # the step's collectives alone: same buckets, dtypes and order, no compute
+            red.stub = True                                    # the same step on identical data with every collective a no-op
+            for _ in range(3):
+                one_step()
+            nocomm_ms = bracket(one_step, n_c)
+            red.stub = False
+            one_step()                                         # (leave the replicas in step with each other again: real sums)
+            comm = {"algorithm": red.algorithm, "exchange_dtype": red.exchange, "buckets": len(red.param_chunks if red.exchange == "bf16" else red.chunks),
+                    "overlap_with_backward": bool(split), "bytes_per_step": red.bytes_per_step(),
+                    "allreduce_alone_ms": alone_ms, "algbw_GBps_alone": red.bytes_per_step() / (alone_ms * 1e-3) / 1e9,
+                    "step_without_collectives_ms": nocomm_ms, "exposed_ms": elapsed / steps * 1e3 - nocomm_ms, "steps_each": n_c,
+                    "note": "exposed_ms = ms_per_step - the same step with the collectives stubbed to no-ops on identical data; "
+                            "allreduce_alone_ms = the same buckets with no compute around them (max over ranks)"}
+
         # ---- secondary figure: forward + criterion + backward only (SURVEY 8-d's strict metric; `value` above also
         # pays for the optimizer and, at N > 1, the gradient exchange) ---------------------------------------------
         n_fb = max(10, min(steps, 50))
@@ -243,9 +275,8 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
             for i in range(n_l):
                 tf = flops[i] / (avg_ms[i] * 1e-3) / 1e12 if avg_ms[i] > 0 else 0.0
                 f.write(f"{i:4d} {LAUNCH_NAMES[kinds[i]]:14s} {PARTS[parts[i]]:10s} {avg_ms[i] * 1e3:9.2f} us {flops[i] / 1e9:9.3f} GFLOP {tf:8.1f} TFLOP/s\n")
-    # every launch that carries GEMM FLOPs: the grouped GEMM launches, or - when the persistent kernels are on - the two
-    # persistent launches (whose time then also holds the attention / LayerNorm items inside: conservative)
-    gemm_idx = [i for i in range(n_l) if kinds[i] in (0, 1, 2, 11, 12)]
+    # every launch that carries GEMM FLOPs: the grouped GEMM launches
+    gemm_idx = [i for i in range(n_l) if kinds[i] in (0, 1, 2)]
     gemm_ms = sum(avg_ms[i] for i in gemm_idx)
     gemm_fl = sum(flops[i] for i in gemm_idx)
     fam_idx = [i for i in gemm_idx if kinds[i] in (0, 1) and parts[i] == 1]
@@ -284,7 +315,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                    "step": ("fwd+CE+bwd (1 hipGraph)" if not split else "fwd+CE+bwd in two hipGraphs") +
                            (f" + {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} grad all-reduce ({stepper.reducer.exchange}" + (", fusion / classifier bucket sent under the encoders' backward)" if split else ")") if world > 1 else "") + " + fused Adam",
                    "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
-                   "launches_per_step": plan.num_launches(), "persistent_kernels": plan.persistent(),
+                   "launches_per_step": plan.num_launches(),
                    "token_rows": plan.T, "plan_shape": [plan.B, plan.L], "packed": bool(plan.packed),
                    "param_shadows": "written by the fused Adam kernel (no parameter casts in the forward)" if eng.wshadow is not None and world == 1
                                     else ("re-cast at the head of every forward" if dtype == "bf16" else None),
@@ -298,10 +329,11 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         "step_tflops": slots_per_s * fb_per_slot / 1e12,
         "step_frac_of_peak": slots_per_s * fb_per_slot / 1e12 / (peak * world),
     }
+    if comm is not None:
+        out["comm"] = comm
     if roofline:
         out["roofline"] = {
-            "bound": "mfma", "kernel": "m2f_gemm16_ring_kernel (bf16: forward / input-gradient launches as 128x128, 128x64 or 64x64 ring tiles; the weight-gradient table launch in its row-major form) or m2f_gemm_kernel (fp32): grouped MFMA GEMM launches of one step"
-                                       + (" [persistent kernels on: m2f_mega_kernel + m2f_gemm16_table_kernel]" if plan.persistent() else ""),
+            "bound": "mfma", "kernel": "m2f_gemm16_ring_kernel (bf16: forward / input-gradient launches as 128x128, 128x64 or 64x64 ring tiles; the weight-gradient table launch in its row-major form) or m2f_gemm_kernel (fp32): grouped MFMA GEMM launches of one step",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None if traffic is None or traffic["_stale"] else float(traffic["traffic_bytes_per_launch"]),
             "traffic_source": None if traffic is None else {"file": traffic["_source"], "stale": traffic["_stale"]},
@@ -348,8 +380,14 @@ def main():
                     help="form the process group (gloo when there is no GPU), check its size against --gpus, print it, exit: "
                          "the launch path without the measurement (tests/test_dp_cpu.py)")
     ap.add_argument("--repeats", type=int, default=5, help="timed brackets of `--steps` steps each (the first one is `value`)")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange all gradients after the whole backward (default: the fusion "
-                    "stack's / classifier's bucket travels under the encoders' backward)")
+    ap.add_argument("--dp-overlap", action="store_true", default=os.environ.get("M2F_DP_OVERLAP", "0") == "1",
+                    help="N > 1: the fusion stack's / classifier's gradient bucket travels under the encoders' backward (the step runs as two "
+                         "hipGraphs).  OFF by default: verified bit for bit against the plain order through gloo staging, never yet run on RCCL "
+                         "with two devices - switch it on once a multi-GPU run has compared the two")
+    ap.add_argument("--no-overlap", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--dp-algorithm", default=os.environ.get("M2F_DP_ALGORITHM", "all_reduce"), choices=list(dp.ALGORITHMS),
+                    help="N > 1: per bucket one all-reduce, or reduce-scatter + all-gather (SURVEY section 5's direct exchange over the "
+                         "fully connected xGMI links)")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 parity mode) leg of the same workload")
     ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
                     help="second single-GPU configuration reported under `secondary` (N = 1 only)")
@@ -388,7 +426,7 @@ def main():
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
                        roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed, repeats=max(1, args.repeats),
-                       overlap=not args.no_overlap)
+                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm)
     if rank == 0:
         out = res
         if world == 1 and args.dtype == "bf16" and not args.no_parity_leg and not args.ragged and not args.packed:

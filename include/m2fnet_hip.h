@@ -102,13 +102,11 @@ int m2f_plan_params_fresh(m2f_plan* plan, int fresh);
 void m2f_plan_destroy(m2f_plan* plan);
 void* m2f_plan_buffer(m2f_plan* plan, int which);
 int m2f_plan_num_launches(m2f_plan* plan, int phase);   /* 0 fwd, 1 loss, 2 bwd */
-/* bf16 plans run the forward launch list and the input-gradient chain of the backward list as ONE persistent
- * ("strip-dataflow") launch each (csrc/mega.h): bit 0 = forward, bit 1 = backward.  0 = launch lists (fp32 mode,
- * dialogues of more than 32 utterances, widths above 1024, or M2F_MEGA=0 in the environment when the plan was built). */
+/* Kept for callers of rounds 2-3, when a plan could run its launch lists as two persistent ("strip-dataflow") launches (measured
+ * slower than the lists and removed in round 4; git history keeps csrc/mega.hip): always 0 = launch lists. */
 int m2f_plan_persistent(m2f_plan* plan);
-/* Sticky give-up record of the persistent kernels: every wait inside them is bounded; a wait that runs out ends the
- * launch and leaves (code, item, strip, counter) here - out8[0..3] forward, out8[4..7] backward.  Synchronous (reads
- * device memory): call it where the host synchronises anyway.  Returns non-zero if either kernel has given up. */
+/* Status record of a plan's kernels: out8 is zeroed and 0 returned - no kernel of the launch lists waits on another workgroup, so
+ * none can give up (the persistent kernels left their bounded-wait record here).  Fails on a NULL / destroyed plan. */
 int m2f_plan_status(m2f_plan* plan, uint32_t* out8);
 
 /* M2FNet.forward (src/model.py:102-145): inputs read from M2F_BUF_TEXT/AUDIO/KEYPAD, logits -> M2F_BUF_LOGITS. */
@@ -144,9 +142,8 @@ int m2f_gather_dialogues(const float* text_table, int d_text, const float* audio
 
 /* Measurement aid: one EAGER m2f_step with a hipEvent pair recorded on `stream` around every launch.  Fills, per
  * launch, kinds[] (0/1/2 = grouped GEMM forward/dgrad/wgrad form, 3/4 attention fwd/bwd, 5/6 LayerNorm fwd/bwd,
- * 7 dropout-mask, 8 criterion, 9 LayerNorm-parameter reduce, 10 bf16 cast / token-transpose copies, 11 / 12 the persistent
- * forward / backward-chain kernel - flops[] then holds the GEMM FLOPs of every op inside; chain launches carry + 32 x their
- * part of the model: 0 modality encoders, 1 fusion stack (FusionAttentionModule, src/model.py:13-20), 2 classifier), ms[]
+ * 7 dropout-mask, 8 criterion, 9 LayerNorm-parameter reduce, 10 bf16 cast / token-transpose copies, 11 / 12 unused (the removed persistent kernels);
+ * chain launches carry + 32 x their part of the model: 0 modality encoders, 1 fusion stack (FusionAttentionModule, src/model.py:13-20), 2 classifier), ms[]
  * (device time) and flops[] (algorithmic FLOPs of the launch, 0 for row-wise kernels).  Synchronises the stream.  Returns the number of launches, or <0. */
 int m2f_step_timed(m2f_plan* plan, float label_smoothing, int use_class_weights, int normalise, m2f_stream_t stream,
                    int max_entries, int* kinds, float* ms, double* flops);

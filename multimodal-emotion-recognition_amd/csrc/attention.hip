@@ -20,10 +20,10 @@
 #include "ops.h"
 #include <cstdlib>
 
-// No floating-point contraction in this file: the launch-list kernels and the persistent kernel (mega.hip) restate the same
-// formulas in different surroundings, and with -ffp-contract=fast (the HIP default) the compiler is free to fuse a*b+c in one
-// of them and not in the other - a 1-ulp difference that would hide real hand-off bugs from the bit-for-bit comparison of
-// the two paths (tests/test_mega_gpu.py).  These kernels are bound by memory or by MFMA, not by VALU multiplies.
+// No floating-point contraction in this file: several kernels restate the same formulas in different surroundings (ring and
+// register-staged GEMM epilogues, fp32 and bf16 attention forms, flat and shadow-writing Adam), and with -ffp-contract=fast (the
+// HIP default) the compiler is free to fuse a*b+c in one of them and not in the other - a 1-ulp difference that would break the
+// bit-for-bit comparisons the tests make between the forms.  These kernels are bound by memory or by MFMA, not by VALU multiplies.
 #pragma clang fp contract(off)
 
 namespace {
@@ -171,6 +171,7 @@ __device__ __forceinline__ f32x4 dot_rows_bf16(const float* arow, const float* b
 
 template <int NT>
 __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) {
+    static_assert(sizeof(AttnBatch) + 56 <= 192 + 512, "m2f_kernarg_warm ranges no longer cover AttnBatch + the hidden arguments");
     m2f_kernarg_warm<0, 8, 192>();                  // the descriptor block (648 B + hidden arguments) in one miss
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_fwd_kernel(const AttnBatch ab) 
 
 template <int NT>
 __global__ __launch_bounds__(NTHR) void m2f_attn_bwd_kernel(const AttnBatch ab) {
+    static_assert(sizeof(AttnBatch) + 56 <= 192 + 512, "m2f_kernarg_warm ranges no longer cover AttnBatch + the hidden arguments");
     m2f_kernarg_warm<0, 8, 192>();                  // the descriptor block (648 B + hidden arguments) in one miss
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

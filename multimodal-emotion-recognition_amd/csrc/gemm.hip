@@ -29,10 +29,10 @@
 #include <type_traits>
 #include <cstring>
 
-// No floating-point contraction in this file: the launch-list kernels and the persistent kernel (mega.hip) restate the same
-// formulas in different surroundings, and with -ffp-contract=fast (the HIP default) the compiler is free to fuse a*b+c in one
-// of them and not in the other - a 1-ulp difference that would hide real hand-off bugs from the bit-for-bit comparison of
-// the two paths (tests/test_mega_gpu.py).  These kernels are bound by memory or by MFMA, not by VALU multiplies.
+// No floating-point contraction in this file: several kernels restate the same formulas in different surroundings (ring and
+// register-staged GEMM epilogues, fp32 and bf16 attention forms, flat and shadow-writing Adam), and with -ffp-contract=fast (the
+// HIP default) the compiler is free to fuse a*b+c in one of them and not in the other - a 1-ulp difference that would break the
+// bit-for-bit comparisons the tests make between the forms.  These kernels are bound by memory or by MFMA, not by VALU multiplies.
 #pragma clang fp contract(off)
 
 // Experiment knobs (register sets in flight).  NOTE: builds that spill VGPRs are NOT safe with the inline-asm staging

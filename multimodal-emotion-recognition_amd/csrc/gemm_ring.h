@@ -3,11 +3,12 @@
 #pragma once
 #include "common.h"
 #include "ops.h"
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
-// (same setting as gemm.hip / mega.hip: the persistent kernels repeat this arithmetic and must round identically)
+// (same setting as gemm.hip: the register-staged kernels repeat this arithmetic and must round identically)
 #pragma clang fp contract(off)
 
 extern long long m2f_g_ring_launches;         // host-side count of ring-form launches (gemm_ring.hip)
@@ -737,6 +738,9 @@ __global__ __launch_bounds__(512) void m2f_gemm16_ring_kernel(const GemmBatch gb
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // role-local ids
     // everything both roles read before the first operand load - tb[], hot[] (bytes 0..735), count .. the hidden launch
     // geometry (2900..3100) - and, for grouped launches, pr[0] / pr[1] (736..1280), which the epilogue reads
+    // (the second range must reach from `count` over the end of the struct into the hidden launch geometry behind it)
+    static_assert(offsetof(GemmBatch, count) >= 2880 - 256 && sizeof(GemmBatch) + 64 <= 2880 - 256 + 512 && offsetof(GemmBatch, pr) + 2 * sizeof(GemmProblem) <= 24 * 64,
+                  "m2f_kernarg_warm ranges no longer cover GemmBatch: recompute them");
     if constexpr (TABLE) m2f_kernarg_warm<0, 8, 2880 - 256>();
     else m2f_kernarg_warm<0, 24, 2880 - 256>();
     // grouped launches: workgroup b walks tiles remap(b), + grid, ... of the launch's tile list; TABLE form: its own list

@@ -17,17 +17,6 @@
 #include "../../include/m2fnet_hip.h"
 #include "common.h"
 #include "ops.h"
-#include "mega.h"
-
-// The persistent strip-dataflow kernels (mega.hip) are PARKED (round 3): correct and bit-identical to the launch lists, but
-// slower (C3 fwd+bwd 3.34 vs 2.70 ms, profiles/r02_bench_c3_bf16_persistent_kernels.json), so the default library is built
-// without them.  `make -C csrc mega` builds libm2fnet_hip_mega.so with them (-DM2F_WITH_MEGA); M2F_LIB=<that> M2F_MEGA=1 runs them.
-#ifndef M2F_WITH_MEGA
-hipError_t m2f_launch_mega(const MegaArgs&, int, int, hipStream_t) { return hipErrorNotSupported; }      // (never reached: no plan turns them on)
-#define M2F_MEGA_AVAILABLE 0
-#else
-#define M2F_MEGA_AVAILABLE 1
-#endif
 
 #ifndef M2F_TABLE_TILE_DEFAULT
 #define M2F_TABLE_TILE_DEFAULT 131      // weight-gradient table launch: see build_plan (M2F_TABLE_TILE)
@@ -282,11 +271,6 @@ struct m2f_plan {
     hipGraphExec_t gexec_part[2] = {nullptr, nullptr};
     float gp_ls[2] = {0.f, 0.f}; int gp_cw[2] = {-1, -1}, gp_norm[2] = {-1, -1}, gp_fresh[2] = {-1, -1};
     std::vector<LnReduceBatch> lnred;
-    // strip-dataflow persistent kernels (mega.h, bf16 mode): the whole forward launch list, and the backward list from
-    // `first` on, as ONE launch each.  M2F_MEGA=0 (read when a plan is built) keeps the launch lists.
-    struct MegaRun { MegaArgs args; bool on = false; int nt = 0, grid = 0, n_ops = 0; size_t first = 0; double flops = 0.0; size_t zero_bytes = 0; };
-    MegaRun mfwd, mbwd;
-    uint32_t* mega_status = nullptr;     // [8]: sticky give-up record of the two runs (zeroed when the plan is created)
     size_t ws_used = 0;
     // graph cache for m2f_step
     hipGraphExec_t gexec = nullptr;
@@ -840,231 +824,6 @@ void to_launches(const m2f_plan& P, const std::vector<Op>& ops, std::vector<Laun
 }
 
 
-// ---- strip-dataflow persistent kernel: item / problem / target tables of one launch list (mega.h) -------------------
-struct MegaTables {
-    std::vector<MegaItem> items;
-    std::vector<GemmProblem> gemm;
-    std::vector<AttnProblem> attn;
-    std::vector<LnProblem> ln;
-    std::vector<MegaDrop> drop;
-    std::vector<uint32_t> need;      // [n_ops][n_strips]
-    int qoff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int n_ops = 0;
-    double flops = 0.0;
-    bool eligible = true;            // every op can run inside the kernel (decided on the real pointers, not in the dry sizing pass)
-};
-
-// Rewrites a chain GEMM problem into the k-contiguous bf16 form the kernel stages (forward: W shadow; input gradient: the
-// W^T shadow).  false: an operand has no 16-byte-stageable bf16 copy (e.g. the [T, n_classes] criterion gradient).
-bool mega_gemm_form(GemmProblem& g, int layout, int T) {
-    if (layout == M2F_LAYOUT_TN || g.M != T) return false;
-    if (layout == M2F_LAYOUT_NN)
-        for (int sgm = 0; sgm < 2; ++sgm) { g.b.q[sgm] = g.b.qt[sgm]; g.b.ldq[sgm] = g.b.ldqt[sgm]; }
-    if (g.a.k[0] != g.b.k[0] || g.a.k[1] != g.b.k[1] || g.a.k[0] <= 0) return false;
-    if ((g.flags & (GF_GELU_OUT | GF_RELU_B)) || g.c8 || g.bias_grad) return false;
-    auto seg_ok = [](const GemmOperand& o) {
-        for (int sgm = 0; sgm < 2; ++sgm) {
-            if (o.k[sgm] == 0) continue;
-            if (!o.q[sgm] || (reinterpret_cast<uintptr_t>(o.q[sgm]) & 15) || (o.ldq[sgm] & 7)) return false;
-            if ((o.k[sgm] & 7) && o.ldq[sgm] != ((o.k[sgm] + 7) & ~7)) return false;      // the pads must be the buffer's own zero pads
-            if (o.ldq[sgm] < o.k[sgm]) return false;
-        }
-        return true;
-    };
-    return seg_ok(g.a) && seg_ok(g.b);
-}
-
-void mega_tables(const m2f_plan& P, const std::vector<Launch>& ls, size_t first, int halves_fwd, int halves_bwd, MegaTables& mt) {
-    const int T = P.T, L = P.L, S = M2F_MEGA_STRIP, n_strips = (T + S - 1) / S;
-    // Item order = op-major, inside an op strip-major (a strip's share of an op finishes as early as possible, so the next
-    // op can start on it while the later strips are still being multiplied).  Optional SKEW (M2F_MEGA_GROUP = strips per
-    // group): the strips are cut into groups and time slot t lists op (t - g) of group g, so that at any moment tiles of
-    // several ops are on the chip.  Measured on MI355X (C3: 3.50 ms fwd+bwd unskewed, 3.86 / 4.01 / 4.23 with groups of
-    // 4 / 2 / 1 strips): the skew multiplies the weight traffic (a panel is re-fetched per group instead of being shared by
-    // all strips while it is hot in L2) and buys nothing, because the waits it was meant to hide are not dependency stalls
-    // (persistent kernel) - so the default is no skew.  Every order here lists an item after all items it
-    // depends on, which is all the kernel needs.
-    const char* genv = getenv("M2F_MEGA_GROUP");
-    const int gs = std::max(1, genv ? atoi(genv) : n_strips), n_groups = (n_strips + gs - 1) / gs;
-    std::vector<uint32_t> done((size_t)n_strips, 0u);          // items of the earlier ops per strip
-    std::vector<std::vector<std::vector<std::pair<MegaItem, int>>>> chunk;     // [op][group] -> (item, queue)
-    int rr = 0;                                                // round-robin queue of the items that read no weight panel
-    for (size_t li = first; li < ls.size(); ++li) {
-        const Launch& l = ls[li];
-        const int op = mt.n_ops++;
-        chunk.emplace_back((size_t)n_groups);
-        for (int s = 0; s < n_strips; ++s) mt.need.push_back(done[s]);
-        std::vector<uint32_t> mine((size_t)n_strips, 0u);
-        auto push = [&](int kind, int prob, int a, int b, int tok_lo, int tok_hi, int queue) {
-            MegaItem it; memset(&it, 0, sizeof(it));
-            it.kind = (uint8_t)kind; it.op = (uint16_t)op; it.prob = (uint16_t)prob; it.a = a; it.b = b;
-            const int s0 = tok_lo / S, s1 = std::min(tok_hi, T - 1) / S;
-            it.s0 = (uint16_t)s0; it.nstrips = (uint8_t)(s1 - s0 + 1);
-            for (int s = s0; s <= s1; ++s) ++mine[s];
-            if (queue < 0) queue = rr++ & 7;
-            chunk.back()[s1 / gs].push_back({it, queue});      // the group of its LAST strip: every strip it reads is in that group or an earlier one
-        };
-        if (op > 65535) mt.eligible = false;
-        switch (l.kind) {
-            case OP_GEMM: {
-                std::vector<std::pair<int, int>> panels;
-                for (int i = 0; i < l.gb.count; ++i) {
-                    GemmProblem g = l.gb.pr[i];
-                    if (!mega_gemm_form(g, l.layout, T)) mt.eligible = false;
-                    mt.flops += 2.0 * g.M * g.N * ((double)g.a.k[0] + g.a.k[1]);
-                    const int prob = (int)mt.gemm.size();
-                    mt.gemm.push_back(g);
-                    for (int np = 0; np < (g.N + 63) / 64; ++np) panels.push_back({prob, np});
-                }
-                if (mt.gemm.size() > 65535) mt.eligible = false;
-                // a weight panel (problem, 64-column block) always goes to the same queue = the same XCD's L2
-                for (int ms = 0; ms < n_strips; ++ms)
-                    for (size_t pn = 0; pn < panels.size(); ++pn)
-                        push(MK_GEMM, panels[pn].first, 64 * ms, 64 * panels[pn].second, S * ms, S * ms + S - 1, (int)(pn & 7));
-                break;
-            }
-            case OP_ATTN_FWD: case OP_ATTN_BWD: {
-                const int halves = l.kind == OP_ATTN_FWD ? halves_fwd : halves_bwd;
-                for (int i = 0; i < l.ab.count; ++i) {
-                    const AttnProblem& ap = l.ab.pr[i];
-                    const int prob = (int)mt.attn.size();
-                    mt.attn.push_back(ap);
-                    const int nbh = P.B * ap.H;
-                    for (int bh0 = 0; bh0 < nbh; bh0 += halves) {
-                        const int cnt = std::min(halves, nbh - bh0);
-                        push(l.kind == OP_ATTN_FWD ? MK_ATTN_FWD : MK_ATTN_BWD, prob, bh0, cnt, (bh0 / ap.H) * L, ((bh0 + cnt - 1) / ap.H + 1) * L - 1, -1);
-                    }
-                }
-                break;
-            }
-            case OP_LN_FWD: case OP_LN_BWD: {
-                for (int i = 0; i < l.lb.count; ++i) {
-                    if (l.lb.pr[i].d > M2F_MEGA_MAX_D) mt.eligible = false;
-                    const int prob = (int)mt.ln.size();
-                    mt.ln.push_back(l.lb.pr[i]);
-                    const int nblk = m2f_ln_row_blocks(T);
-                    for (int b0 = 0; b0 < nblk; b0 += 2)
-                        push(l.kind == OP_LN_FWD ? MK_LN_FWD : MK_LN_BWD, prob, b0, std::min(2, nblk - b0), b0 * M2F_LN_ROWS_PER_BLOCK,
-                             (b0 + 2) * M2F_LN_ROWS_PER_BLOCK - 1, -1);
-                }
-                break;
-            }
-            case OP_DROPOUT: {
-                for (int which = 0; which < (l.dptr2 ? 2 : 1); ++which) {
-                    MegaDrop d; d.x = which ? l.dptr2 : l.dptr; d.T = l.dT; d.d = l.dd; d.ld = l.dld; d.site = which ? l.dsite2 : l.dsite;
-                    const int prob = (int)mt.drop.size();
-                    mt.drop.push_back(d);
-                    for (int r0 = 0; r0 < l.dT; r0 += 16) push(MK_DROPOUT, prob, r0, std::min(16, l.dT - r0), r0, r0 + 15, -1);
-                }
-                break;
-            }
-        }
-        for (int s = 0; s < n_strips; ++s) done[s] += mine[s];
-    }
-    // merge: slot t = op + group; deal the global order to the 8 queues (each queue keeps the global order)
-    std::vector<MegaItem> q[8];
-    for (int t = 0; t < mt.n_ops + n_groups - 1; ++t)
-        for (int g = 0; g < n_groups; ++g) {
-            const int op = t - g;
-            if (op < 0 || op >= mt.n_ops) continue;
-            for (const auto& e : chunk[op][g]) q[e.second].push_back(e.first);
-        }
-    for (int x = 0; x < 8; ++x) {
-        mt.qoff[x] = (int)mt.items.size();
-        mt.items.insert(mt.items.end(), q[x].begin(), q[x].end());
-    }
-    mt.qoff[8] = (int)mt.items.size();
-    if (mt.attn.size() > 65535 || mt.ln.size() > 65535) mt.eligible = false;
-}
-
-// Allocates the device tables of one run in the arena (same sizes in the dry sizing pass) and, with real pointers, uploads
-// them and fills run.args.
-void mega_place(m2f_plan& P, Arena& ar, bool real, const MegaTables& mt, m2f_plan::MegaRun& run, size_t first, int attn_w,
-                int bwd_fast, int halves_fwd, int halves_bwd, uint32_t* status) {
-    const int n_strips = (P.T + M2F_MEGA_STRIP - 1) / M2F_MEGA_STRIP;
-    MegaItem* d_items = ar.alloc<MegaItem>(mt.items.size() + 1);
-    GemmProblem* d_gemm = ar.alloc<GemmProblem>(mt.gemm.size() + 1);
-    AttnProblem* d_attn = ar.alloc<AttnProblem>(mt.attn.size() + 1);
-    LnProblem* d_ln = ar.alloc<LnProblem>(mt.ln.size() + 1);
-    MegaDrop* d_drop = ar.alloc<MegaDrop>(mt.drop.size() + 1);
-    uint32_t* d_need = ar.alloc<uint32_t>(mt.need.size() + 1);
-    uint32_t* d_queue = ar.alloc<uint32_t>((size_t)(8 + n_strips) * 32);     // [8 ticket counters | n_strips progress counters], one 128-byte line each
-    uint32_t* d_progress = d_queue + 8 * 32;
-    run.on = false;
-    if (!real || !mt.eligible || mt.items.empty()) return;
-    bool ok = true;
-    auto up = [&](void* dst, const void* src, size_t bytes) { if (bytes) ok = ok && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
-    up(d_items, mt.items.data(), mt.items.size() * sizeof(MegaItem));
-    up(d_gemm, mt.gemm.data(), mt.gemm.size() * sizeof(GemmProblem));
-    up(d_attn, mt.attn.data(), mt.attn.size() * sizeof(AttnProblem));
-    up(d_ln, mt.ln.data(), mt.ln.size() * sizeof(LnProblem));
-    up(d_drop, mt.drop.data(), mt.drop.size() * sizeof(MegaDrop));
-    up(d_need, mt.need.data(), mt.need.size() * sizeof(uint32_t));
-    if (!ok) return;
-    MegaArgs& a = run.args;
-    memset(&a, 0, sizeof(a));
-    a.items = d_items; a.n_strips = n_strips; a.queue = d_queue;
-    for (int x = 0; x < 9; ++x) a.qoff[x] = mt.qoff[x];
-    a.gemm = d_gemm; a.attn = d_attn; a.ln = d_ln; a.drop = d_drop; a.need = d_need; a.progress = d_progress; a.status = status;
-    a.B = P.B; a.L = P.L; a.T = P.T; a.key_pad = static_cast<const uint8_t*>(P.bufs[M2F_BUF_KEYPAD]);
-    a.rng = P.rng; a.drop_thresh = P.drop_thresh; a.drop_scale = P.drop_scale; a.ln_eps = P.cfg.ln_eps; a.sh = P.sh;
-    a.attn_w = attn_w; a.attn_bwd_fast = bwd_fast; a.attn_halves_fwd = halves_fwd; a.attn_halves_bwd = halves_bwd;
-    run.on = true; run.nt = (P.L + 15) / 16; run.grid = 256; run.n_ops = mt.n_ops; run.first = first; run.flops = mt.flops;
-    run.zero_bytes = (size_t)(8 + n_strips) * 32 * sizeof(uint32_t);
-}
-
-void build_mega(m2f_plan& P, Arena& ar, bool real) {
-    const char* env = getenv("M2F_MEGA");
-    // (packed plans keep the launch lists: the persistent kernels' strips assume whole dialogues of L rows)
-    const bool want = !P.packed && (M2F_MEGA_DEFAULT ? !(env && env[0] == '0') : (env && env[0] == '1'));
-    const int NT = (P.L + 15) / 16, Lp = 16 * NT;
-    int W = 16;
-    for (const std::vector<Launch>* ls : {&P.fwd, &P.bwd})
-        for (const Launch& l : *ls)
-            if (l.kind == OP_ATTN_FWD || l.kind == OP_ATTN_BWD)
-                for (int i = 0; i < l.ab.count; ++i) W = std::max(W, (l.ab.pr[i].hd + 15) & ~15);
-    const size_t hf = (size_t)3 * Lp * (W + 2) * sizeof(float);
-    // same rule as attention.hip's launcher, so both paths take the same backward form
-    const int bwd_fast = (W <= 128 && ((size_t)5 * Lp * (W + 2) + Lp) * sizeof(float) <= 160 * 1024) ? 1 : 0;
-    const size_t hb = ((size_t)(bwd_fast ? 5 : 4) * Lp * (W + 2) + Lp) * sizeof(float);
-    const int halves_fwd = 2 * hf <= M2F_MEGA_LDS_WORK ? 2 : 1, halves_bwd = 2 * hb <= M2F_MEGA_LDS_WORK ? 2 : 1;
-    const bool fits = NT <= M2F_MEGA_MAX_NT && hf <= M2F_MEGA_LDS_WORK && hb <= M2F_MEGA_LDS_WORK;
-    uint32_t* status = ar.alloc<uint32_t>(16);
-    P.mega_status = status;
-    unsigned long long* prof = ar.alloc<unsigned long long>(2 * 64);     // diagnostic builds (-DM2F_MEGA_PROF) only
-    const bool use = M2F_MEGA_AVAILABLE && real && want && fits && P.prec == M2F_PREC_BF16;
-    {
-        MegaTables mt;
-        mega_tables(P, P.fwd, 0, halves_fwd, halves_bwd, mt);
-        mega_place(P, ar, use, mt, P.mfwd, 0, W, bwd_fast, halves_fwd, halves_bwd, status);
-        P.mfwd.args.prof = prof;
-    }
-    if (P.train) {
-        // the longest tail of the backward list whose every op can run inside the kernel (the head - the input gradient of
-        // the last classifier layer, whose operand is the unshadowed [T, n_classes] criterion gradient - stays a launch)
-        size_t first = P.bwd.size();
-        if (use) {
-            while (first > 0) {
-                const Launch& l = P.bwd[first - 1];
-                bool ok = true;
-                if (l.kind == OP_GEMM)
-                    for (int i = 0; i < l.gb.count; ++i) { GemmProblem g = l.gb.pr[i]; ok = ok && mega_gemm_form(g, l.layout, P.T); }
-                if (l.kind == OP_LN_FWD || l.kind == OP_LN_BWD)
-                    for (int i = 0; i < l.lb.count; ++i) ok = ok && l.lb.pr[i].d <= M2F_MEGA_MAX_D;
-                if (!ok) break;
-                --first;
-            }
-        } else {
-            first = std::min<size_t>(P.bwd.size(), 1);       // sizing pass: every op after the first (an upper bound of the tables)
-        }
-        MegaTables mt;
-        mega_tables(P, P.bwd, first, halves_fwd, halves_bwd, mt);
-        mega_place(P, ar, use && first < P.bwd.size(), mt, P.mbwd, first, W, bwd_fast, halves_fwd, halves_bwd, status + 4);
-        P.mbwd.args.prof = prof + 64;
-    }
-    if (real && status) (void)hipMemset(status, 0, 16 * sizeof(uint32_t));
-    if (real && prof) (void)hipMemset(prof, 0, 128 * sizeof(unsigned long long));
-}
 
 // bf16 mode: which fp32 results does nobody read?  Every GEMM / attention output in the workspace is written twice - fp32 and
 // its bf16 shadow - but GEMM operands, the weight-gradient table and (M2F_ATTN_BF16 bits) the attention slabs are staged from the
@@ -1076,8 +835,6 @@ void build_mega(m2f_plan& P, Arena& ar, bool real) {
 int mark_unread_fp32(m2f_plan& P, const float* wsf, size_t ws_floats, const std::vector<GemmProblem>& table_probs, bool poison) {
     const char* e = getenv("M2F_SKIP_F32");
     if (e && atoi(e) == 0) return 0;
-    const char* mg = getenv("M2F_MEGA");
-    if (mg && mg[0] == '1') return 0;                 // (the parked persistent kernels read the fp32 buffers)
     std::vector<uint8_t> read32((ws_floats + 63) / 64, 0), read16((ws_floats + 63) / 64, 0);      // fp32 readers / bf16-shadow readers
     auto span = [&](const float* p, size_t rows, size_t ld, size_t cols, size_t& lo, size_t& hi) {
         if (!p || p < wsf || p >= wsf + ws_floats || rows == 0) return false;
@@ -1549,7 +1306,6 @@ int build_plan(m2f_plan& P, char* ws_base) {
     if (P.prec == M2F_PREC_BF16 && ws_base != nullptr && (!P.train || (table_ok && table_rc))) {
         if (int r = mark_unread_fp32(P, reinterpret_cast<const float*>(ws_base), ws_floats, tprobs, true)) return r;
     }
-    build_mega(P, bld.ar, ws_base != nullptr);
     P.ws_used = bld.ar.off;
     return 0;
 }
@@ -1622,14 +1378,6 @@ int do_loss(m2f_plan& P, float ls, int use_cw, int normalise, hipStream_t s) {
     return 0;
 }
 
-// One persistent launch in place of a launch list (mega.h): m2f_launch_mega re-arms the counters, then runs the kernel.
-int run_mega(m2f_plan::MegaRun& run, int prof_kind, hipStream_t s) {
-    if (g_prof) g_prof->begin(prof_kind, run.flops);
-    M2F_HIP(m2f_launch_mega(run.args, run.nt, run.grid, s));
-    if (g_prof) g_prof->end();
-    return 0;
-}
-
 // part 0 / 1 of the split backward (see m2f_plan::bwd_head)
 int do_backward_part(m2f_plan& P, int part, hipStream_t s) {
     if (!P.split_ok) return fail("m2f_step_part: this plan has no split backward (bf16 train plans with the row-major weight-gradient table only)");
@@ -1648,10 +1396,7 @@ int do_backward_part(m2f_plan& P, int part, hipStream_t s) {
 
 int do_backward(m2f_plan& P, hipStream_t s) {
     if (!P.train || !P.grads) return fail("m2f_backward: plan was created without train=1 / gradient buffer");
-    if (P.mbwd.on) {
-        if (int r = run_launches(P, P.bwd, s, 0, P.mbwd.first)) return r;
-        if (int r = run_mega(P.mbwd, 12, s)) return r;
-    } else if (int r = run_launches(P, P.bwd, s)) return r;
+    if (int r = run_launches(P, P.bwd, s)) return r;
     if (P.wg_nt) {
         if (g_prof) g_prof->begin(10, 0.0);
         if (P.wg_trans.blocks > 0) M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
@@ -1798,7 +1543,7 @@ void* m2f_plan_buffer(m2f_plan* plan, int which) {
     return plan->bufs[which];
 }
 
-int m2f_plan_persistent(m2f_plan* plan) { return plan ? (plan->mfwd.on ? 1 : 0) | (plan->mbwd.on ? 2 : 0) : 0; }
+int m2f_plan_persistent(m2f_plan*) { return 0; }        // (the persistent strip-dataflow kernels of rounds 2-3 are gone: git history)
 
 /* diagnostic (not part of the ABI header): where the activation shadows of a bf16 plan live */
 int m2f_dbg_shadow_map(m2f_plan* plan, const float** ws_base, uint16_t** shadow, int64_t* floats) {
@@ -1910,31 +1655,14 @@ int m2f_plan_skipped_copies(m2f_plan* plan) { return plan ? plan->n_no_f32 : -1;
 int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
     if (!plan || !out8) return fail("m2f_plan_status: NULL plan (destroyed?) or output");
     for (int i = 0; i < 8; ++i) out8[i] = 0u;
-    if (!plan->mega_status || !(plan->mfwd.on || plan->mbwd.on)) return 0;
-    M2F_HIP(hipMemcpy(out8, plan->mega_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (out8[0] || out8[4]) {
-        const int w = out8[0] ? 0 : 4;
-        return fail(std::string("persistent ") + (w ? "backward" : "forward") + " kernel gave up (code " + std::to_string(out8[w]) +
-                    "): item " + std::to_string(out8[w + 1]) + " waited on strip " + std::to_string(out8[w + 2]) + " at " +
-                    std::to_string(out8[w + 3]));
-    }
-    return 0;
-}
-
-/* diagnostic (-DM2F_MEGA_PROF builds): the persistent kernels' tick table, [2 runs][8 kinds][8 fields]; clears it */
-int m2f_plan_prof(m2f_plan* plan, unsigned long long* out128) {
-    if (!plan) return fail("m2f_plan_prof: NULL plan (destroyed?)");
-    if (!plan->mfwd.on || !plan->mfwd.args.prof) return fail("no persistent kernels in this plan");
-    M2F_HIP(hipMemcpy(out128, plan->mfwd.args.prof, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    M2F_HIP(hipMemset(plan->mfwd.args.prof, 0, 128 * sizeof(unsigned long long)));
-    return 0;
+    return 0;            // (no kernel of the launch lists can give up: nothing waits on another workgroup)
 }
 
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (!plan) return -1;
-    if (phase == 0) return (int)((plan->mfwd.on ? 1 : plan->fwd.size()) + (plan->params_fresh ? 0 : plan->param_casts.size()) + plan->input_casts.size());
+    if (phase == 0) return (int)(plan->fwd.size() + (plan->params_fresh ? 0 : plan->param_casts.size()) + plan->input_casts.size());
     if (phase == 1) return 2;
-    return (int)((plan->mbwd.on ? plan->mbwd.first + 1 : plan->bwd.size()) + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() + plan->wg_casts.size() : plan->wg.size()) + plan->lnred.size());
+    return (int)(plan->bwd.size() + (plan->wg_nt ? (plan->wg_trans.blocks > 0 ? 2 : 1) + plan->wg_rest.size() + plan->wg_casts.size() : plan->wg.size()) + plan->lnred.size());
 }
 
 static int do_forward(m2f_plan& P, hipStream_t s) {
@@ -1946,7 +1674,6 @@ static int do_forward(m2f_plan& P, hipStream_t s) {
             if (g_prof) g_prof->end();
         }
     }
-    if (P.mfwd.on) return run_mega(P.mfwd, 11, s);
     return run_launches(P, P.fwd, s);
 }
 
@@ -1999,7 +1726,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
     return 0;
 }
 
-int64_t m2f_plan_split_offset(m2f_plan* plan) { return plan && plan->split_ok && !plan->mbwd.on && !plan->mfwd.on ? plan->split_offset : 0; }
+int64_t m2f_plan_split_offset(m2f_plan* plan) { return plan && plan->split_ok ? plan->split_offset : 0; }
 
 int m2f_step_part(m2f_plan* plan, int part, float label_smoothing, int use_class_weights, int normalise, int use_graph,
                   m2f_stream_t stream) {
@@ -2007,7 +1734,7 @@ int m2f_step_part(m2f_plan* plan, int part, float label_smoothing, int use_class
     m2f_plan& P = *plan;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!P.train || part < 0 || part > 1) return fail("m2f_step_part needs a train plan and part 0 or 1");
-    if (!P.split_ok || P.mfwd.on || P.mbwd.on) return fail("m2f_step_part: this plan has no split backward");
+    if (!P.split_ok) return fail("m2f_step_part: this plan has no split backward");
     auto body = [&]() -> int {
         if (part == 0) {
             if (P.use_dropout) M2F_HIP(m2f_launch_rng_advance(P.rng, s));

@@ -8,10 +8,10 @@
 #include "ops.h"
 #include <algorithm>
 
-// No floating-point contraction in this file: the launch-list kernels and the persistent kernel (mega.hip) restate the same
-// formulas in different surroundings, and with -ffp-contract=fast (the HIP default) the compiler is free to fuse a*b+c in one
-// of them and not in the other - a 1-ulp difference that would hide real hand-off bugs from the bit-for-bit comparison of
-// the two paths (tests/test_mega_gpu.py).  These kernels are bound by memory or by MFMA, not by VALU multiplies.
+// No floating-point contraction in this file: several kernels restate the same formulas in different surroundings (ring and
+// register-staged GEMM epilogues, fp32 and bf16 attention forms, flat and shadow-writing Adam), and with -ffp-contract=fast (the
+// HIP default) the compiler is free to fuse a*b+c in one of them and not in the other - a 1-ulp difference that would break the
+// bit-for-bit comparisons the tests make between the forms.  These kernels are bound by memory or by MFMA, not by VALU multiplies.
 #pragma clang fp contract(off)
 
 namespace {
@@ -77,7 +77,8 @@ __device__ __forceinline__ bool is_vec(const void* p, int d) {
 
 template <int NV>
 __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
-    m2f_kernarg_warm<0, 8, 136>();                  // the descriptor block (520 B + hidden arguments) in one miss
+    static_assert(sizeof(LnBatch) + 64 <= 136 + 512, "m2f_kernarg_warm ranges no longer cover LnBatch + the hidden arguments");
+    m2f_kernarg_warm<0, 8, 136>();                  // the descriptor block (552 B + hidden arguments) in one miss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pi = 0;
 #pragma unroll
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
 
 template <int NV>
 __global__ __launch_bounds__(256) void m2f_ln_bwd_kernel(const LnBatch lb) {
-    m2f_kernarg_warm<0, 8, 136>();                  // the descriptor block (520 B + hidden arguments) in one miss
+    static_assert(sizeof(LnBatch) + 64 <= 136 + 512, "m2f_kernarg_warm ranges no longer cover LnBatch + the hidden arguments");
+    m2f_kernarg_warm<0, 8, 136>();                  // the descriptor block (552 B + hidden arguments) in one miss
     extern __shared__ __attribute__((aligned(16))) float red[];      // [LN_WAVES][2][dpad]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pi = 0;

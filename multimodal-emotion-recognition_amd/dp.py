@@ -98,24 +98,81 @@ def broadcast_from_rank0(values: Sequence[float], device=None) -> List[float]:
     return t.cpu().tolist()
 
 
+ALGORITHMS = ("all_reduce", "rs_ag")
+
+
+def _rs_ag_host(host: torch.Tensor, group) -> None:
+    """reduce-scatter + all-gather of a host tensor whose length divides by the world size (in place)."""
+    w = dist.get_world_size(group)
+    shard = torch.empty(host.numel() // w, dtype=host.dtype)
+    dist.reduce_scatter_tensor(shard, host, op=dist.ReduceOp.SUM, group=group)
+    dist.all_gather_into_tensor(host, shard, group=group)
+
+
 class _StagedWork:
     """gloo has no device collectives on this build: a CUDA tensor is summed through a host copy.  Same interface as the
     Work object of an asynchronous collective (only `wait`), same stream semantics as RCCL's: after `wait()` the current
     stream may read the result."""
 
+    def __init__(self, t: torch.Tensor, group, algorithm: str = "all_reduce"):
+        self.t, self.group, self.algorithm = t, group, algorithm
+
+    def wait(self) -> None:
+        host = self.t.detach().to("cpu", torch.float32)        # (synchronises with the current stream: the producers are done)
+        if self.algorithm == "rs_ag" and host.numel() % dist.get_world_size(self.group) == 0:
+            _rs_ag_host(host, self.group)
+        else:
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        self.t.copy_(host.to(self.t.dtype))
+
+
+class _HostPairWork:
     def __init__(self, t: torch.Tensor, group):
         self.t, self.group = t, group
 
     def wait(self) -> None:
-        host = self.t.detach().to("cpu", torch.float32)        # (synchronises with the current stream: the producers are done)
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-        self.t.copy_(host.to(self.t.dtype))
+        if self.t.numel() % dist.get_world_size(self.group) == 0 and self.t.is_contiguous():
+            _rs_ag_host(self.t, self.group)
+        else:
+            dist.all_reduce(self.t, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def _all_reduce_sum(t: torch.Tensor, group=None):
-    """Asynchronous SUM all-reduce of `t` -> an object with wait()."""
-    if t.is_cuda and dist.get_backend(group) == "gloo":
-        return _StagedWork(t, group)
+class _NoWork:
+    def wait(self) -> None:
+        pass
+
+
+class _PairWork:
+    """reduce-scatter then all-gather, both asynchronous on the collective's stream (which runs them in issue order)."""
+
+    def __init__(self, works, keep):
+        self.works, self.keep = works, keep                # `keep`: the shard buffer must outlive the collectives
+
+    def wait(self) -> None:
+        for w in self.works:
+            w.wait()
+        self.keep = None
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None, algorithm: str = "all_reduce"):
+    """Asynchronous SUM all-reduce of `t` -> an object with wait().
+
+    algorithm = "rs_ag" (SURVEY section 5's direct form): ``reduce_scatter_tensor`` into this rank's 1/W shard followed by
+    ``all_gather_into_tensor`` back into `t` - on 8 fully connected GPUs every rank exchanges 1/W of the bucket with each of
+    its 7 peers, one peer per xGMI link, instead of passing 2 (W-1)/W of it around a ring.  Same sums as the all-reduce for
+    two ranks (a + b), the same up to the order of the partial sums beyond.  Buckets whose length does not divide by W (never
+    the case for W = 2, 4, 8: bucket edges are 64-float aligned) keep the plain all-reduce."""
+    if dist.get_backend(group) == "gloo":
+        if t.is_cuda:
+            return _StagedWork(t, group, algorithm)
+        if algorithm == "rs_ag":                   # gloo runs asynchronous collectives in no particular order: pair them at wait()
+            return _HostPairWork(t, group)
+    w = dist.get_world_size(group)
+    if algorithm == "rs_ag" and w > 1 and t.numel() % w == 0 and t.is_contiguous():
+        shard = torch.empty(t.numel() // w, dtype=t.dtype, device=t.device)
+        w1 = dist.reduce_scatter_tensor(shard, t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        w2 = dist.all_gather_into_tensor(t, shard, group=group, async_op=True)
+        return _PairWork([w1, w2], shard)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
@@ -126,15 +183,17 @@ class GradReducer:
     collective's own stream (``async_op=True``), so a caller that produces gradients back-to-front can start
     reducing finished chunks while the rest is still being computed."""
 
-    def __init__(self, buf: torch.Tensor, n_params: int, group=None, n_buckets: int = 1, exchange: str = "fp32"):
-        """exchange = "fp32": the buffer itself is all-reduced (exact sum of the ranks' fp32 gradients).
+    def __init__(self, buf: torch.Tensor, n_params: int, group=None, n_buckets: int = 1, exchange: str = "fp32",
+                 algorithm: str = "all_reduce"):
+        """algorithm = "all_reduce" | "rs_ag" (see `_all_reduce_sum`).
+        exchange = "fp32": the buffer itself is all-reduced (exact sum of the ranks' fp32 gradients).
         exchange = "bf16": the parameter gradients travel as bf16 (half the xGMI bytes; the 64-float tail with the
         loss terms stays fp32 in its own small collective) and the optimizer reads the reduced bf16 buffer directly -
         the usual mixed-precision trade (each rank's gradient rounded once to bf16, ring partial sums in bf16), offered
         for the bf16 compute mode only."""
         assert buf.numel() >= n_params + 3 and buf.dim() == 1
-        assert exchange in ("fp32", "bf16")
-        self.buf, self.n, self.group, self.exchange = buf, n_params, group, exchange
+        assert exchange in ("fp32", "bf16") and algorithm in ALGORITHMS
+        self.buf, self.n, self.group, self.exchange, self.algorithm = buf, n_params, group, exchange, algorithm
         n_buckets = max(1, int(n_buckets))
         edges = [round(i * buf.numel() / n_buckets / 64) * 64 for i in range(n_buckets)] + [buf.numel()]
         self.chunks = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
@@ -153,6 +212,29 @@ class GradReducer:
         self.buf16 = torch.empty(n_params, dtype=torch.bfloat16, device=buf.device) if exchange == "bf16" else None
         self._work = []
         self._starts = None
+        self.stub = False
+
+    def _sum(self, t: torch.Tensor, plain: bool = False):
+        """One bucket's collective (`plain`: the 64-float tail, always a plain all-reduce).  `self.stub` (bench.py's
+        exposed-communication measurement): the same step with every collective replaced by a no-op on identical data."""
+        if self.stub:
+            return _NoWork()
+        return _all_reduce_sum(t, self.group, "all_reduce" if plain else self.algorithm)
+
+    def exchange_only(self) -> None:
+        """The step's collectives alone - same buckets, same order, same dtypes, no compute around them (bench.py `comm`)."""
+        if not dist.is_initialized():
+            return
+        if self.exchange == "bf16":
+            work = [self._sum(self.buf[self.n:], plain=True)] + [self._sum(self.buf16[a:b]) for a, b in reversed(self.param_chunks)]
+        else:
+            work = [self._sum(self.buf[a:b]) for a, b in reversed(self.chunks)]
+        for w in work:
+            w.wait()
+
+    def bytes_per_step(self) -> int:
+        """Payload one rank hands to the collectives per step (the algorithm decides how many times it crosses a link)."""
+        return self.n * 2 + (self.buf.numel() - self.n) * 4 if self.exchange == "bf16" else self.buf.numel() * 4
 
     def align_to(self, tensor_starts) -> None:
         """Move the bucket edges to the nearest parameter-tensor boundaries (offsets into the flat buffer): the fused optimizer can
@@ -195,7 +277,7 @@ class GradReducer:
     def all_reduce(self, async_op: bool = False) -> None:
         if not dist.is_initialized():
             return                                   # single process: nothing to exchange
-        self._work = [_all_reduce_sum(self.buf[a:b], self.group) for a, b in self.chunks]
+        self._work = [self._sum(self.buf[a:b]) for a, b in self.chunks]
         if not async_op:
             self.wait()
 
@@ -213,12 +295,12 @@ class GradReducer:
             return
         if self.exchange == "bf16":
             tail = self.buf[self.n:]
-            work_tail = _all_reduce_sum(tail, self.group)   # (loss, den, num): fp32
+            work_tail = self._sum(tail, plain=True)          # (loss, den, num): fp32
             order = list(reversed(self.param_chunks))
             work = []
             for a, b in order:
                 self.buf16[a:b].copy_(self.buf[a:b])                     # one rounding per rank, on the device
-                work.append(_all_reduce_sum(self.buf16[a:b], self.group))
+                work.append(self._sum(self.buf16[a:b]))
 
             def wait(i):
                 if i == 0:
@@ -227,7 +309,7 @@ class GradReducer:
             optimizer.step_ranges(order, before_each=wait, grads=self.buf16)
             return
         order = list(reversed(self.chunks))
-        work = [_all_reduce_sum(self.buf[a:b], self.group) for a, b in order]
+        work = [self._sum(self.buf[a:b]) for a, b in order]
         optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
 
     def reduce_and_step_split(self, optimizer, run_rest, split: int) -> None:
@@ -247,15 +329,15 @@ class GradReducer:
         head = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]            # encoder part of the parameters, in buckets
         if self.exchange == "bf16":
             tail = self.buf[self.n:]
-            work_tail = _all_reduce_sum(tail, self.group)                       # (loss, den, num): fp32
+            work_tail = self._sum(tail, plain=True)                              # (loss, den, num): fp32
             self.buf16[split:self.n].copy_(self.buf[split:self.n])
-            work_first = _all_reduce_sum(self.buf16[split:self.n], self.group) if self.n > split else None
+            work_first = self._sum(self.buf16[split:self.n]) if self.n > split else None
             run_rest()
             order = [(split, self.n)] + list(reversed(head))
             work = [work_first]
             for a, b in order[1:]:
                 self.buf16[a:b].copy_(self.buf[a:b])
-                work.append(_all_reduce_sum(self.buf16[a:b], self.group))
+                work.append(self._sum(self.buf16[a:b]))
 
             def wait(i):
                 if i == 0:
@@ -264,10 +346,10 @@ class GradReducer:
                     work[i].wait()
             optimizer.step_ranges(order, before_each=wait, grads=self.buf16)
             return
-        work_first = _all_reduce_sum(self.buf[split:], self.group)               # fusion stack + classifier + (loss, den, num)
+        work_first = self._sum(self.buf[split:])               # fusion stack + classifier + (loss, den, num)
         run_rest()
         order = [(split, self.buf.numel())] + list(reversed(head))
-        work = [work_first] + [_all_reduce_sum(self.buf[a:b], self.group) for a, b in order[1:]]
+        work = [work_first] + [self._sum(self.buf[a:b]) for a, b in order[1:]]
         optimizer.step_ranges(order, before_each=lambda i: work[i].wait())
 
     @property
@@ -312,16 +394,40 @@ class DataParallelStep:
     """One optimizer step of dialogue-sharded data-parallel training:
     m2f_step(normalise=0) -> tail <- (den, num) -> all-reduce -> fused Adam with grad_scale = global den."""
 
-    def __init__(self, model, optimizer, group=None, n_buckets: int = 4, exchange: str = "fp32", overlap: bool = True):
+    def __init__(self, model, optimizer, group=None, n_buckets: int = 4, exchange: str = "fp32", overlap: Optional[bool] = None,
+                 algorithm: str = "all_reduce"):
         """overlap: with more than one rank, run the step in two parts (runtime.Plan.step_part) and put the all-reduce of the
         fusion stack's / classifier's gradients on the wire before the encoders' backward starts (plans that cannot be split -
-        fp32 mode - exchange after the whole backward as before)."""
-        self.model, self.optimizer, self.overlap = model, optimizer, overlap
+        fp32 mode - exchange after the whole backward as before).  None = the environment's M2F_DP_OVERLAP (default OFF: the
+        path is verified bit for bit against overlap off through gloo staging, tests/test_dp_multirank_gpu.py, but has not yet
+        run on RCCL with two devices - no multi-GPU box has been available to this repository).
+        algorithm: "all_reduce" | "rs_ag" (GradReducer)."""
+        if overlap is None:
+            overlap = os.environ.get("M2F_DP_OVERLAP", "0") == "1"
+        self.model, self.optimizer, self.overlap = model, optimizer, bool(overlap)
+        self._split: Optional[int] = None
         eng = model.engine()
         eng.ensure_grad()
-        self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets, exchange)
+        self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets, exchange, algorithm)
         self.reducer.align_to(o for (_, o, _, _) in eng.items)      # buckets of whole tensors: the optimizer keeps the bf16 parameter shadows current
         optimizer.grad_scale = self.reducer.global_den
+
+    def split_for(self, plan) -> int:
+        """First element of the flat gradient buffer that is final after part 0 of a step, or 0 when the step is not split.  The
+        value is a property of the parameter layout (the fusion stack's first parameter), not of a batch shape, and every rank
+        must use the same one or their collectives differ in number and size: it is taken once - from the first plan, or, on a
+        rank whose very first shard is empty, from a one-dialogue plan built for the purpose - and a plan that disagrees later
+        raises instead of issuing a different schedule."""
+        if not (self.overlap and self.reducer.world() > 1):
+            return 0
+        if self._split is None:
+            if plan is None:
+                plan = self.model.engine().plan(1, 16, True, self.model.training and self.model.m2f_config.dropout > 0.0)
+            self._split = int(plan.split_offset())
+        elif plan is not None and int(plan.split_offset()) != self._split:
+            raise RuntimeError(f"mer_amd.dp: this plan splits its backward at {plan.split_offset()}, earlier plans at {self._split}; "
+                               "the ranks' gradient collectives would no longer match")
+        return self._split
 
     def __call__(self, text, audio, mask, emotion, label_smoothing: float = 0.1, class_weights=None,
                  use_graph: bool = True) -> torch.Tensor:
@@ -333,7 +439,12 @@ class DataParallelStep:
             with torch.cuda.stream(eng.stream):
                 self.reducer.zero_contribution()
                 eng.publish_grads()
-                self.reducer.reduce_and_step(self.optimizer)
+                # the SAME bucket schedule as the ranks that hold dialogues (number, order and sizes of the collectives)
+                split = self.split_for(None)
+                if split > 0:
+                    self.reducer.reduce_and_step_split(self.optimizer, lambda: None, split)
+                else:
+                    self.reducer.reduce_and_step(self.optimizer)
                 loss = self.reducer.global_loss()
             cur.wait_stream(eng.stream)
             return loss
@@ -343,7 +454,7 @@ class DataParallelStep:
                             mask, emotion)
             if class_weights is not None:
                 plan.class_w[: class_weights.numel()].copy_(class_weights)
-            split = plan.split_offset() if (self.overlap and self.reducer.world() > 1) else 0
+            split = self.split_for(plan)
             if split > 0:
                 cw = class_weights is not None
                 plan.step_part(0, label_smoothing, cw, False, use_graph)              # tail <- (loss, den, num); fusion / classifier gradients final

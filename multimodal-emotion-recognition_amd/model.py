@@ -177,15 +177,17 @@ class _Engine:
         # bf16 mode: ONE buffer of bf16 parameter shadows (W and W^T of every 2-D parameter) for all plans, kept current by
         # FusedAdam.step itself (m2f_adam_step_shadowed).  `_fresh_token` = the parameters' version counters at the moment the
         # optimizer last wrote the shadows: any later in-place change through torch (load_state_dict, a foreign optimizer,
-        # p.mul_()) moves the counters, the plans then re-cast the shadows at the head of their forward as before.  Writes that
-        # bypass the counters (p.data..., flat_parameters()[...] = ...) need `invalidate_shadows()`.  M2F_SHARED_SHADOWS=0: off.
+        # p.mul_(), writes through the flat buffer or its views) moves the counters, the plans then re-cast the shadows at the head of
+        # their forward as before.  Writes that bypass the counters (p.data...) need `invalidate_shadows()`; `flat_parameters()` calls it.  M2F_SHARED_SHADOWS=0: off.
         self.wshadow: Optional[torch.Tensor] = None
         self._fresh_token = None
         if self.precision == runtime.BF16 and os.environ.get("M2F_SHARED_SHADOWS", "1") != "0":
             self.wshadow = runtime.param_shadow_buffer(self.cfg, device)
 
     def _version_token(self):
-        return sum(p._version for (p, _, _, _) in self.items)
+        # the parameters' own counters + the flat buffer's (shared by every view of it: a write through `flat_parameters()` or a
+        # slice of it moves that one; the fused Adam kernels write through raw pointers and move neither)
+        return (sum(p._version for (p, _, _, _) in self.items), self.flat._version)
 
     def mark_shadows_fresh(self) -> None:
         self._fresh_token = self._version_token()
@@ -423,7 +425,12 @@ class M2FNet(nn.Module):
             self._engine.invalidate_shadows()
 
     def flat_parameters(self) -> torch.Tensor:
-        return self.engine().flat
+        """The flat fp32 parameter buffer (reference state_dict order).  Handing it out invalidates the bf16 parameter shadows:
+        the caller may write through it (in-place writes also move its version counter, which the freshness token includes;
+        writes that bypass the counters - ``.data`` - are caught by this call having invalidated)."""
+        eng = self.engine()
+        eng.invalidate_shadows()
+        return eng.flat
 
     def flat_gradients(self) -> torch.Tensor:
         return self.engine().ensure_grad()

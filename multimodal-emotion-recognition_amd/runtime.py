@@ -299,11 +299,11 @@ class Plan:
         return self.workspace[off: off + n * esize].view(dtype).view(*shape)
 
     def persistent(self) -> int:
-        """bit 0 / bit 1: the forward / backward chain runs as one persistent strip-dataflow launch (csrc/mega.h)."""
+        """Always 0 since round 4 (the persistent strip-dataflow kernels were removed; kept for callers that still ask)."""
         return lib().m2f_plan_persistent(self._h())
 
     def check_status(self) -> None:
-        """Raises if a persistent kernel gave up on a bounded wait (synchronises with the device)."""
+        """Raises on a destroyed plan; nothing else can be wrong since the persistent kernels (bounded waits) were removed."""
         out = (c_uint32 * 8)()
         check(lib().m2f_plan_status(self._h(), out), "m2f_plan_status")
 
@@ -472,15 +472,10 @@ class Plan:
         return [(kinds[i], ms[i], fl[i]) for i in range(n)]
 
     def close(self) -> None:
-        """Destroy the plan (captured graph, launch lists) and drop its workspace.  A plan that ran the (parked) persistent
-        kernels reports a bounded wait that ran out here at the latest - such a launch ends with wrong results, not a hang."""
+        """Destroy the plan (captured graph, launch lists) and drop its workspace."""
         h = getattr(self, "handle", None)
         if h and _lib is not None:
-            try:
-                if _lib.m2f_plan_persistent(h):
-                    self.check_status()
-            finally:
-                _lib.m2f_plan_destroy(h)
+            _lib.m2f_plan_destroy(h)
         self.handle = None
         self.workspace = None
 

@@ -122,7 +122,9 @@ def main(config=None):
     optimizer = FusedAdam(model, lr=config.solver.lr, weight_decay=config.solver.weight_decay)
     if world > 1:
         model.dp_step = dp.DataParallelStep(model, optimizer, n_buckets=int(_runtime(config, "grad_buckets", 4)),
-                                            exchange=_runtime(config, "grad_exchange", "fp32"))
+                                            exchange=_runtime(config, "grad_exchange", "fp32"),
+                                            overlap=bool(_runtime(config, "grad_overlap", False)),
+                                            algorithm=_runtime(config, "grad_algorithm", "all_reduce"))
     if config.wandb.enabled and rank == 0:
         start_wandb(config)
     lr_scheduler = build_scheduler(config.solver, optimizer)
@@ -250,6 +252,22 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
     return running / len(dl_train)
 
 
+def _rank_share(dl_val, rank, world):
+    """Batches r, r + W, ... of the validation loader.  A torch DataLoader is re-built over exactly those index batches, so a rank
+    neither collates nor uploads the batches it would discard; that needs the batches to be the same on every rank, i.e. no
+    shuffling (the reference validates with shuffle: False, src/config.yaml:66).  Other loaders (DeviceLoader) are iterated and
+    the foreign batches skipped."""
+    if world == 1:
+        return dl_val
+    if isinstance(dl_val, torch.utils.data.DataLoader) and dl_val.batch_sampler is not None:
+        if not isinstance(dl_val.sampler, torch.utils.data.SequentialSampler):
+            raise ValueError("validation over several ranks deals whole batches to the ranks: val.data_loader.shuffle must be False")
+        mine = list(dl_val.batch_sampler)[rank::world]
+        return torch.utils.data.DataLoader(dl_val.dataset, batch_sampler=mine, collate_fn=dl_val.collate_fn,
+                                           num_workers=dl_val.num_workers, pin_memory=dl_val.pin_memory)
+    return (b for i, b in enumerate(dl_val) if i % world == rank)
+
+
 def validate(model, dl_val, criterion, device):
     """-> (mean batch loss, accuracy, weighted_f1); scores by the per-batch rule of ``metrics.BatchScores``.
     With several ranks the replicas are identical and the rule is a plain mean over the reference's batches
@@ -260,9 +278,7 @@ def validate(model, dl_val, criterion, device):
     model.eval()
     scores, loss_total = BatchScores(), 0.0
     with torch.inference_mode():
-        for i, batch in enumerate(tqdm(dl_val, total=len(dl_val), desc="Validation", disable=rank != 0)):
-            if i % world != rank:
-                continue
+        for batch in tqdm(_rank_share(dl_val, rank, world), total=(len(dl_val) - rank + world - 1) // world, desc="Validation", disable=rank != 0):
             text, audio, emotion, padding_mask = move_batch(batch, device)
             logits = model(text, audio, padding_mask)
             loss_total += criterion(logits.permute(0, 2, 1), emotion).item()

@@ -14,7 +14,7 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 # multi-process GPU tests (marker `dp2`): the rank processes of tests/dp_worker.py, started at the END OF COLLECTION - i.e. before
 # this process has made any GPU call (a process that has initialised the GPU must not start other programs on this pool; counting
 # devices does not initialise it) - and only when such a test was selected on a box with a GPU
-DP2 = {"proc": None, "dir": None, "log": None}
+DP2 = {"proc": None, "dir": None, "log": None, "rc": None}
 
 
 def pytest_configure(config):
@@ -40,6 +40,13 @@ def pytest_collection_finish(session):
                                     "--master-addr", "127.0.0.1", "--master-port", str(port),
                                     os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env, stdout=log, stderr=subprocess.STDOUT)
     DP2["dir"], DP2["log"] = out, log
+    # ... and WAIT for it here, still before this process has touched the GPU: the two rank processes must not share the device
+    # with this process's own GPU tests (a fault or an out-of-memory kill could not be attributed, timing tests would get noisy)
+    try:
+        DP2["rc"] = DP2["proc"].wait(timeout=900)
+    except subprocess.TimeoutExpired:
+        DP2["proc"].kill()
+        DP2["rc"] = -9
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -52,16 +59,14 @@ def pytest_sessionfinish(session, exitstatus):
 
 @pytest.fixture(scope="session")
 def dp2_results():
-    """The two ranks' result files (waits for the worker processes; skips when they were not started)."""
+    """The two ranks' result files (the worker processes have exited before the first test ran; skips when they were not started)."""
     import torch
     p = DP2["proc"]
     if p is None:
         pytest.skip("no GPU on this box: the 2-rank worker processes were not started")
-    try:
+    rc = DP2.get("rc")
+    if rc is None:                                          # (not reached: collection_finish waits)
         rc = p.wait(timeout=600)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        rc = -9
     DP2["log"].flush()
     log = open(os.path.join(DP2["dir"], "worker.log")).read()[-4000:]
     errs = "".join(open(os.path.join(DP2["dir"], f)).read() for f in sorted(os.listdir(DP2["dir"])) if f.startswith("error_rank"))

@@ -57,7 +57,7 @@ def loop_config(tmp_dir, dropout=0.0):
     return cfg
 
 
-def run_training_loop(cfg, device, world, rank):
+def run_training_loop(cfg, device, world, rank, precision="fp32", exchange="fp32", overlap=None):
     """2+ epochs over 7 dialogues in global batches of 3 (the last batch holds ONE dialogue: rank 1's shard is empty),
     validation over 5 dialogues in batches of 2 (3 batches: rank 0 scores two, rank 1 one), early stopping with patience 1."""
     import dataset as ds
@@ -70,11 +70,11 @@ def run_training_loop(cfg, device, world, rank):
     if world > 1:
         dl_train = dp.ShardedLoader(dl_train, rank, world)
     torch.manual_seed(0)
-    model = tr.M2FNet(cfg.model).to(device)
+    model = tr.M2FNet(cfg.model, precision=precision).to(device)
     crit = tr.M2FCrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)
     opt = tr.FusedAdam(model, lr=cfg.solver.lr, weight_decay=cfg.solver.weight_decay)
     if world > 1:
-        model.dp_step = dp.DataParallelStep(model, opt, n_buckets=3, exchange="fp32")
+        model.dp_step = dp.DataParallelStep(model, opt, n_buckets=3, exchange=exchange, overlap=overlap)
     hist = tr.training_loop(model, dl_train, dl_val, crit, opt, None, 0, cfg, device)
     torch.cuda.synchronize()
     return {"history": hist, "params": model.flat_parameters().detach().cpu().clone()}
@@ -133,9 +133,9 @@ def main():
             losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(4)]
             torch.cuda.synchronize()
             plan = next(iter(mb.engine().plans.values()))
+            fresh = mb.engine().shadows_fresh()           # (before flat_parameters(): handing the buffer out invalidates)
             res["D"][(overlap, exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(),
-                                             "split": plan.split_offset(), "exchange": sb.reducer.exchange,
-                                             "fresh": mb.engine().shadows_fresh()}
+                                             "split": plan.split_offset(), "exchange": sb.reducer.exchange, "fresh": fresh}
     # ... and the same steps with per-plan shadows re-cast at every forward (round-2 behaviour): the bucket-wise shadow-writing
     # optimizer must leave the same parameters
     os.environ["M2F_SHARED_SHADOWS"] = "0"
@@ -147,9 +147,29 @@ def main():
         sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange=exchange, overlap=True)
         losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(4)]
         torch.cuda.synchronize()
-        res["D"][("recast", exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(),
-                                          "fresh": mb.engine().shadows_fresh()}
+        fresh = mb.engine().shadows_fresh()
+        res["D"][("recast", exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(), "fresh": fresh}
     os.environ.pop("M2F_SHARED_SHADOWS", None)
+
+    # ---- E: the direct exchange (reduce-scatter + all-gather per bucket) against the all-reduce: two ranks add a + b either way --
+    res["E"] = {}
+    for algorithm in ("all_reduce", "rs_ag"):
+        for overlap, exchange in ((False, "fp32"), (True, "bf16"), (False, "bf16")):
+            torch.manual_seed(0)
+            mb = M2FNet(cfg, precision="bf16").to(device).train()
+            mb.load_state_dict({k: v.to(device) for k, v in synth.make_state_dict(cfg).items()})
+            ob = FusedAdam(mb, lr=1e-3, weight_decay=0.01)
+            sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange=exchange, overlap=overlap, algorithm=algorithm)
+            losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(3)]
+            torch.cuda.synchronize()
+            res["E"][(algorithm, overlap, exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone()}
+
+    # ---- F: the training loop in bf16 mode with the overlapped bf16 exchange: the last global batch leaves rank 1's shard EMPTY,
+    # and the empty rank must issue the same collectives (tail, fusion / classifier bucket, encoder buckets) as rank 0 ----------
+    res["F"] = {}
+    for overlap in (True, False):
+        cfg_f = loop_config(os.path.join(out_dir, f"loop_bf16_{int(overlap)}"))
+        res["F"][overlap] = run_training_loop(cfg_f, device, world, rank, precision="bf16", exchange="bf16", overlap=overlap)
 
     # ---- C: the training loop of src/train.py under two ranks -----------------------------------------------------
     cfg_loop = loop_config(os.path.join(out_dir, "loop_dp"))

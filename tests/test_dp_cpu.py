@@ -81,6 +81,47 @@ def _worker(rank, world, port, q):
                       and float(buf3[0]) == float(torch.tensor(0.1 * (rank + 1))))       # fp32 gradients left untouched
     out["pipelined_ok"] = (all(a == total and b == total for _, _, a, b in seen) and seen[0][1] == buf2.numel()
                            and sorted((lo, hi) for lo, hi, _, _ in seen) == sorted(red2.chunks))
+    # the direct exchange (reduce-scatter + all-gather per bucket) gives the sums of the all-reduce, fp32 and bf16
+    rs_ok = True
+    for exchange in ("fp32", "bf16"):
+        sums = {}
+        for algorithm in dp.ALGORITHMS:
+            g5 = torch.Generator().manual_seed(5 + rank)
+            b5 = torch.cat([torch.randn(4096, generator=g5), torch.full((dp.TAIL,), float(rank + 1))])
+            red5 = dp.GradReducer(b5, 4096, n_buckets=3, exchange=exchange, algorithm=algorithm)
+            got = []
+
+            class Opt5:
+                def step_ranges(self, ranges, before_each=None, grads=None):
+                    for i, (lo, hi) in enumerate(ranges):
+                        before_each(i)
+                        got.append((lo, hi, (grads if grads is not None else b5)[lo:min(hi, 4096)].float().clone()))
+            red5.reduce_and_step(Opt5())
+            sums[algorithm] = (got, float(b5[4096 + 1]))
+        a, b = sums["all_reduce"], sums["rs_ag"]
+        rs_ok = rs_ok and a[1] == b[1] == total and len(a[0]) == len(b[0]) == 3
+        rs_ok = rs_ok and all(x[:2] == y[:2] and torch.equal(x[2], y[2]) for x, y in zip(a[0], b[0]))
+    out["rs_ag_ok"] = rs_ok
+    # split exchange with an EMPTY rank: rank 1 contributes zeros and has nothing to run between the first bucket and the rest, but
+    # issues the same collectives - the sums pair up bucket by bucket
+    for exchange in ("fp32", "bf16"):
+        b6 = torch.cat([(torch.arange(2048) % 128).float() / 16.0,           # (exact in bf16)
+                        torch.tensor([0.0, 3.0, 6.0]), torch.zeros(dp.TAIL - 3)])
+        red6 = dp.GradReducer(b6, 2048, n_buckets=3, exchange=exchange)
+        if rank == 1:
+            red6.zero_contribution()
+        got6, ran = [], []
+
+        class Opt6:
+            def step_ranges(self, ranges, before_each=None, grads=None):
+                for i, (lo, hi) in enumerate(ranges):
+                    before_each(i)
+                    got6.append((lo, hi, (grads if grads is not None else b6)[lo:min(hi, 2048)].float().clone()))
+        red6.reduce_and_step_split(Opt6(), (lambda: ran.append(1)) if rank == 0 else (lambda: None), 1280)
+        want = (torch.arange(2048) % 128).float() / 16.0
+        ok6 = got6[0][:2] == (1280, 2048 if exchange == "bf16" else b6.numel()) and sorted(x[0] for x in got6)[0] == 0
+        ok6 = ok6 and all(torch.equal(x[2], want[x[0]:min(x[1], 2048)]) for x in got6) and float(b6[2048 + 1]) == 3.0
+        out["empty_split_ok_" + exchange] = bool(ok6 and (ran == [1] if rank == 0 else ran == []))
     means = [torch.zeros(1) for _ in range(world)]
     dist.all_gather(means, local_mean.detach().reshape(1))
     out["mean_of_means"] = float(torch.stack(means).mean())
@@ -110,6 +151,9 @@ def test_two_rank_gloo_global_denominator():
     assert r0["max_time"] == 2.0 and res[1]["max_time"] == 2.0
     assert r0["pipelined_ok"] and res[1]["pipelined_ok"]
     assert r0["bf16_ok"] and res[1]["bf16_ok"]
+    assert r0["rs_ag_ok"] and res[1]["rs_ag_ok"]
+    for r in (0, 1):
+        assert res[r]["empty_split_ok_fp32"] and res[r]["empty_split_ok_bf16"], res[r]
 
 
 def test_shard_dialogues_partition():

@@ -98,3 +98,29 @@ def test_overlapped_exchange_equals_exchange_after_backward(dp2_results):
         c = r0["D"][("recast", exchange)]
         assert a["fresh"] and b["fresh"] and not c["fresh"]
         assert a["losses"] == c["losses"] and torch.equal(a["params"], c["params"])
+
+
+def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce(dp2_results):
+    """`GradReducer(algorithm="rs_ag")`: per bucket a reduce-scatter into the rank's 1/W shard and an all-gather back (SURVEY section 5's
+    direct exchange) instead of one all-reduce.  Two ranks add the same two numbers either way: bit-identical steps, with and without
+    the overlapped first bucket, fp32 and bf16 exchange."""
+    (r0, r1), _ = dp2_results
+    for overlap, exchange in ((False, "fp32"), (True, "bf16"), (False, "bf16")):
+        a, b = r0["E"][("all_reduce", overlap, exchange)], r0["E"][("rs_ag", overlap, exchange)]
+        assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+        assert torch.equal(a["params"], b["params"])
+        assert torch.equal(b["params"], r1["E"][("rs_ag", overlap, exchange)]["params"])
+        assert a["losses"][-1] < a["losses"][0]
+
+
+def test_empty_shard_follows_the_overlapped_bucket_schedule(dp2_results):
+    """bf16 mode, bf16 exchange, `overlap=True`, and a last global batch with ONE dialogue: rank 1 holds nothing and has never
+    built a plan for that shape.  It must still issue the collectives rank 0 issues - tail, the fusion stack's / classifier's
+    bucket, then the encoder buckets cut from [0, split) - or the sums pair up wrongly (or RCCL hangs).  The run ends, both
+    replicas hold the same parameters, and they are those of the run that exchanges after the whole backward."""
+    (r0, r1), _ = dp2_results
+    on0, on1, off0 = r0["F"][True], r1["F"][True], r0["F"][False]
+    assert on0["history"] == on1["history"] and torch.equal(on0["params"], on1["params"])
+    assert len(on0["history"]["loss_values"]) >= 2
+    assert on0["history"] == off0["history"]
+    assert torch.equal(on0["params"], off0["params"])

@@ -147,8 +147,19 @@ def test_stale_shadows_are_never_used():
     assert not eng.shadows_fresh()
     half = {k: v * 0.5 for k, v in sd2.items()}
     assert torch.equal(eval_logits(m), eval_logits(_model(cfg, half)))
-    # (3) a write torch cannot see needs the explicit call
+    # (3) a write through the flat buffer: handing the buffer out invalidates, and an in-place write through a handle taken
+    # EARLIER moves the flat buffer's version counter, which the freshness token includes
     m.flat_parameters().mul_(2.0)
+    assert not eng.shadows_fresh()
+    assert torch.equal(eval_logits(m), ref)
     assert eng.shadows_fresh()
+    eng.flat.mul_(0.5)                                                 # (no call to flat_parameters(): the counter alone)
+    assert not eng.shadows_fresh()
+    assert torch.equal(eval_logits(m), eval_logits(_model(cfg, half)))
+    eng.flat[: 64].mul_(1.0)                                           # a view of it
+    assert not eng.shadows_fresh()
+    # (4) a write torch cannot see (.data) needs the explicit call
+    assert torch.equal(eval_logits(m), eval_logits(_model(cfg, half))) and eng.shadows_fresh()
+    eng.flat.data.mul_(2.0)
     m.invalidate_shadows()
     assert torch.equal(eval_logits(m), ref)

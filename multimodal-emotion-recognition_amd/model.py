@@ -187,7 +187,9 @@ class _Engine:
     def _version_token(self):
         # the parameters' own counters + the flat buffer's (shared by every view of it: a write through `flat_parameters()` or a
         # slice of it moves that one; the fused Adam kernels write through raw pointers and move neither)
-        return (sum(p._version for (p, _, _, _) in self.items), self.flat._version)
+        # (an engine first built under torch.inference_mode() holds an inference tensor: no counter, and no in-place writes outside
+        # inference mode either)
+        return (sum(p._version for (p, _, _, _) in self.items), 0 if self.flat.is_inference() else self.flat._version)
 
     def mark_shadows_fresh(self) -> None:
         self._fresh_token = self._version_token()

@@ -75,6 +75,12 @@ def test_bench_plan_fp32_matches_oracle(workload):
         assert float((g - r).abs().max()) <= 0.1 * float(r.abs().max()) + 2e-7, (k, float((g - r).abs().max()), float(r.abs().max()))
 
 
+# bf16-mode gradient direction per tensor against the fp32 oracle (measured worst over all tensors, round 4: see the asserts' messages
+# when they fail): cosine >= 0.99 everywhere; the +-1 probe digest within this fraction of the tensor's gradient norm
+COS_MIN = {"c2": 0.99, "c3": 0.99, "c2p": 0.99}
+DIGEST_MAX = {"c2": 0.25, "c3": 0.25, "c2p": 0.25}
+
+
 @pytest.mark.parametrize("workload", ["c2", "c3", "c2p"])
 def test_bench_plan_bf16_within_stated_tolerance(workload):
     cfg, sd, batch = _setup(workload)
@@ -91,13 +97,26 @@ def test_bench_plan_bf16_within_stated_tolerance(workload):
     agree = (logits.argmax(2) == ref_logits.argmax(2))[valid].float().mean().item()
     assert agree >= 0.97, agree
     checked = 0
+    keys = list(sd.keys())
+    worst_cos, worst_dig = (1.0, ""), (0.0, "")
     for k, p in m.named_parameters():
-        rn = float(ref_grads[k].double().norm())
+        r = ref_grads[k].double()
+        rn = float(r.norm())
         if rn > 1e-3:
-            gn = float(p.grad.double().norm())
+            g = p.grad.detach().cpu().double()
+            gn = float(g.norm())
             assert abs(gn - rn) <= 0.08 * rn, (k, gn, rn)
+            # direction, not only length: cosine of the whole tensor against the oracle's gradient ...
+            cos = float((g * r).sum() / (gn * rn))
+            worst_cos = min(worst_cos, (cos, k))
+            # ... and the +-1 probe digest of the fp32 test (a random projection: its error is ~ |g - r|, i.e. sqrt(2 (1 - cos)) rn)
+            probe = synth.digest_vector(tuple(g.shape), 3, keys.index(k)).double()
+            dig = abs(float((g * probe).sum()) - float((r * probe).sum())) / rn
+            worst_dig = max(worst_dig, (dig, k))
             checked += 1
     assert checked >= 60, checked
+    assert worst_cos[0] >= COS_MIN[workload], worst_cos
+    assert worst_dig[0] <= DIGEST_MAX[workload], worst_dig
 
 
 def test_bf16_adam_trajectory_tracks_fp32():

@@ -251,6 +251,18 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1,
  * pad columns zero).  In bf16 mode a launch whose operands all have one stages from them (half the bytes per CU).
  * splitk_ws / splitk_tickets (nullable): scratch for in-launch split-K of launches too small to fill the chip:
  * splitk_max_tiles * 4 * 64*64 floats and splitk_max_tiles ZEROED uint32 tickets (re-armed by the kernel). */
+/* The 256x256-tile bf16 GEMM on the eight-phase schedule (csrc/gemm_p8.h; round 4), bf16 operands handed over directly - the kernel
+ * the weight-gradient table launch (rc = 1) and the text encoder's launches (rc = 0) run, for kernel-level tests and measurements.
+ *   rc = 0: C[M,N] = act(A[M,K] B[N,K]^T + bias) + res   (nn.Linear forward: src/feature_extractors/text/model.py:16-21's encoder
+ *           layers); K % 64 == 0; act 0 none, 1 ReLU, 2 GELU
+ *   rc = 1: C[M,N] = A[K,M]^T B[K,N]   (weight gradient dW = dY^T X of every nn.Linear in src/model.py: reduction over the token rows),
+ *           relu_a / relu_b on the operands, bias_grad[M] = column sums of A (nullable); runs as a one-problem table launch whose table,
+ *           tile records and per-workgroup ranges are written to `scratch` (device memory, >= 64 KiB + 4 bytes per tile) for n_wg
+ *           workgroups (<= 0: 256); scratch_bytes < 0: `scratch` (of -scratch_bytes bytes) still holds the tables of an identical earlier call.
+ * Returns 0, or < 0 when the shape / alignment is not this kernel's (no fallback). */
+int m2f_gemm_p8(int rc, int M, int N, int K, const uint16_t* a, int lda, const uint16_t* b, int ldb, float* c, int ldc,
+                const float* bias, const float* res, int ldres, int act, int relu_a, int relu_b, float* bias_grad,
+                void* scratch, int64_t scratch_bytes, int n_wg, m2f_stream_t stream);
 /* softmax(q k^T / sqrt(hd) + key_padding_mask) v per (dialogue, head) (nn.MultiheadAttention inside
  * src/model.py:8,14,61,73); probs receives P^T per head, padded to Lp = 16*ceil(L/16). */
 int m2f_attention_fwd(int B, int L, int H, int hd, const float* q, int ldq, const float* k, int ldk,

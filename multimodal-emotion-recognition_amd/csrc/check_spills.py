@@ -28,7 +28,7 @@ for line in open(path, errors="replace"):
         if m:
             cur["scratch"] = int(m.group(1))
 if ring:
-    kernels = [r for r in rows if "m2f_gemm16_ring_kernel" in r["name"]]
+    kernels = [r for r in rows if "m2f_gemm16_ring_kernel" in r["name"] or "m2f_gemm_p8_kernel" in r["name"]]
     if not kernels:
         sys.exit(f"check_spills: no ring kernel found in {path} - did the remark format change?")
     bad = [r for r in kernels if r.get("scratch", 0) > 0 or r.get("vgpr_spill", 0) > 0]

@@ -1263,6 +1263,12 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
         // RoBERTa-large geometry 50.2 -> 43.4 ms per forward, base 17.4 -> 14.5 (threshold 512 tiles; 15.0 at 1,024; no
         // launch of the M2FNet step is that large).
         static const int ring256_min = getenv("M2F_RING256_MIN") ? atoi(getenv("M2F_RING256_MIN")) : 512;      // tiles of 256x128
+        // Round 4: from one chip-filling round of 256 x 256 tiles on, the eight-phase form (gemm_p8.h: all eight waves load and multiply,
+        // continuous prefetch stream across tiles): 32,768 x 1,024 x 1,024 752 TFLOP/s against ~460 for the 256x128 ring form.
+        // M2F_P8=0 switches it off, M2F_P8_MIN moves the threshold (tiles of 256x256).
+        static const int p8_on = getenv("M2F_P8") ? atoi(getenv("M2F_P8")) : 1;
+        static const int p8_min = getenv("M2F_P8_MIN") ? atoi(getenv("M2F_P8_MIN")) : 256;
+        if (ring && p8_on && auto_tile && count_tiles(256, 256) >= p8_min && m2f_gemm_p8_ok(gb)) return m2f_p8_launch_kc(gb, stream);
         if (ring && auto_tile && count_tiles(256, 128) >= ring256_min && m2f_gemm_ring256_ok(gb)) return m2f_launch_gemm_ring(gb, 256, 128, stream);
         // (what the 256x128 ring form cannot take - it has bias / ReLU / GELU / residual epilogues only - keeps the register-staged
         // 256x128 build from 1,024 such tiles on: RoBERTa-large geometry 52.3 vs 54.0 ms with 128x128 ring tiles)
@@ -1482,7 +1488,7 @@ extern "C" int m2f_dbg_read(unsigned long long* out) {
 
 hipError_t m2f_launch_gemm_table(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.table || !gb.tile_prob || gb.total_tiles <= 0) return hipErrorInvalidValue;
-    if (gb.table_tile >= 129 && gb.table_tile <= 131) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
+    if (gb.table_tile >= 129 && gb.table_tile <= 132) return m2f_launch_gemm_ring_table(gb, stream);                              // 128x128 tiles, ring form
     if (gb.table_tile == 256) return launch_table16<256, 128, 64, M2F_T256_D, false>(gb, stream);
     if (gb.table_tile == 128) return launch_table16<128, 128, 64, 3, false>(gb, stream);
     if (gb.table_tile == 64) return launch_table16<64, 64, 128, 2, true>(gb, stream);

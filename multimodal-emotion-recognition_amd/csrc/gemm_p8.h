@@ -1,0 +1,613 @@
+// 256x256 bf16 GEMM tiles on the EIGHT-PHASE schedule (cdna_hip_programming.md section 5, "The 256^2 8-phase template"): device code +
+// launch templates.  Round 4.  Replaces the 4-producer / 4-consumer ring form (gemm_ring.h) where a launch is large enough that the
+// main loop, not the launch's fixed cost, sets its time: the weight-gradient table launch (row-major RC operands) and the in-loop text
+// encoder's launches (k-contiguous KC operands, M = utterances x tokens).
+//
+// Why another form.  In the ring form four waves only move bytes and four multiply, one MFMA wave per SIMD: its k-loops run at
+// 1,530-2,130 cycles per 256x128x64 k-tile for 1,024 cycles of MFMA, i.e. 31-33 % of the bf16 peak at
+// best.  Here all eight waves load AND multiply:
+//   * tile 256 x 256 x 64, wave (wr, wc) = (w >> 2, w & 3) owns rows {wr 64 .. +63} u {128 + wr 64 .. +63} x columns {wc 32 .. +31} u
+//     {128 + wc 32 .. +31}: one 64 x 32 quadrant out of each (A half, B half) pair - 128 accumulator registers;
+//   * LDS = 2 buffers x (A0, A1, B0, B1) half-tiles of 16 KiB = 128 KiB, filled by LDS-DMA (buffer_load ... lds, no staging registers),
+//     every wave moving 1/8 of each half-tile (two 1 KiB pieces);
+//   * a k-tile is FOUR phases = the four quadrants (A0 B0, A0 B1, A1 B1, A1 B0); a phase = {fragment reads of the half that is new
+//     (12 / 4 / 8 / 0 ds_reads) + ONE half-tile of prefetch (2 LDS-DMA pieces per wave)} - barrier - {16 MFMAs 16x16x32} - barrier.
+//     The waves of the lower half (wr = 1: the SIMD partners of wr = 0) run ONE BARRIER BEHIND, so on every SIMD one wave multiplies
+//     while its partner reads and stages;
+//   * the prefetch stream runs three half-tiles ahead of the single counted wait per k-tile (s_waitcnt vmcnt(6) in phase 4) and is
+//     CONTINUOUS across the output tiles of a workgroup's list: while the last k-tiles of one tile are multiplied the first of the
+//     next are already landing, and the epilogue is nothing but the stores (a lane holds four consecutive columns: 16-byte stores,
+//     no LDS pass), drained under the next tile's k-loop.
+// Hazards (placement, not luck - cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  every wave waits vmcnt(6) in the load segment of phase 4; all of k-tile t + 1 was issued before the three youngest half-
+//        tiles, so after the barrier that ends the LOWER half's phase-4 load segment every wave's pieces of t + 1 have landed; the
+//        first reads of t + 1 come after that barrier for both halves.
+//   WAR  B0 is read in phase 1 (retired by lgkmcnt(8) BEFORE the phase's first barrier) and re-staged in phase 2; A0 is read in phase
+//        1 and re-staged in phase 3; B1 read in 2, re-staged in 4; A1 read in 3, re-staged in phase 1 of the next k-tile - always
+//        two barriers after the reads of BOTH halves have been waited for.
+// Per wave all pieces of one LDS region are written by the same wave and LDS-DMA completes in issue order, so re-staging never
+// overtakes an older (range-checked, zero-filling) piece of the same region.
+#pragma once
+#include "gemm_ring.h"
+
+namespace {
+
+struct P8Cfg {
+    static constexpr int BM = 256, BN = 256, BK = 64;
+    static constexpr int HALF = 128 * BK * 2;          // one operand half-tile: 128 rows (KC) or features (RC) x 64 k, 16 KiB
+    static constexpr int BUF = 4 * HALF;               // A0 | A1 | B0 | B1
+    static constexpr int LDS = 2 * BUF;                // 128 KiB
+};
+
+// max(f, floor) on bf16 pairs read as int16 pairs (one v_pk_max_i16 per dword): floor = 0 is ReLU (gemm_ring.h, ring_relu_bf16x2),
+// floor = 0x8000 (-32768) leaves every value as it is - the choice is a block-uniform OPERAND, not a branch
+__device__ __forceinline__ bf16x8 p8_floor8(bf16x8 f, uint32_t floor2) {
+    typedef short p8_s16x2 __attribute__((ext_vector_type(2)));
+    ring_u32x4 w = __builtin_bit_cast(ring_u32x4, f);
+    const p8_s16x2 fl = __builtin_bit_cast(p8_s16x2, floor2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(p8_s16x2, (uint32_t)w[e]), fl));
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// One 1 KiB LDS-DMA piece (64 lanes x 16 bytes to LDS address `lds` + 16 lane) issued from INLINE ASM: with the builtin hipcc knows the
+// instruction writes LDS and answers every later ds_read of the wave with s_waitcnt vmcnt(0) - the prefetch stream would be drained
+// four times per k-tile.  Hidden in asm, the pieces are ordered against the fragment reads by the kernel's own counted vmcnt + barriers
+// (header comment); M0 is written in the statement that uses it (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void p8_dma16(const ring_u32x4& rsrc, unsigned lds, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rsrc) : "memory");
+}
+// raw buffer descriptor (stride 0, range-checked against `bytes`), all words provably uniform
+__device__ __forceinline__ ring_u32x4 p8_rsrc(const void* q, unsigned bytes) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+    ring_u32x4 r;
+    r.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    r.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32)) & 0xFFFFu;
+    r.z = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+// What both the prefetch stream and the multiplying side need of the tile at position `bpos` of this workgroup's sequence - read with
+// SCALAR loads (constant address space): a vector load here would sit in the vmcnt queue between the stream's pieces.
+struct P8Desc {
+    const uint16_t* aq; const uint16_t* bq;
+    int M, N, K, lda, ldb, pi, m0, n0;
+    uint32_t flags;
+};
+template <bool TABLE>
+__device__ __forceinline__ P8Desc p8_desc(const GemmBatch& gb, int bpos) {
+    P8Desc D;
+    if constexpr (TABLE) {
+        typedef const __attribute__((address_space(4))) uint32_t* c_u32p;
+        typedef const __attribute__((address_space(4))) GemmProblem* c_probp;
+        const uint32_t rec = *((c_u32p)(gb.tile_rec) + bpos);
+        D.pi = (int)(rec & 0xFFFFu); D.m0 = (int)((rec >> 16) & 0xFFu) * P8Cfg::BM; D.n0 = (int)(rec >> 24) * P8Cfg::BN;
+        c_probp P = (c_probp)(gb.table) + D.pi;
+        D.aq = P->a.q[0]; D.bq = P->b.q[0]; D.M = P->M; D.N = P->N; D.K = P->a.k[0]; D.lda = P->a.ldq[0]; D.ldb = P->b.ldq[0];
+        D.flags = P->flags;
+    } else {
+        D.pi = ring_problem_of(gb, bpos);
+        const GemmHot& H = gb.hot[D.pi];
+        D.aq = H.aq[0]; D.bq = H.bq[0]; D.M = H.M; D.N = H.N; D.K = H.k[0]; D.lda = H.ldaq[0]; D.ldb = H.ldbq[0]; D.flags = H.flags;
+        const int tl = bpos - H.tile_begin, tiles_m = (H.M + P8Cfg::BM - 1) / P8Cfg::BM;
+        D.m0 = (tl % tiles_m) * P8Cfg::BM; D.n0 = (tl / tiles_m) * P8Cfg::BN;
+    }
+    return D;
+}
+
+#ifdef P8_TIMING
+// diagnostic build (make p8timing; tools/p8_timing.py): accumulated s_memtime differences of waves 0 and 4 of workgroup 0, per phase:
+// [wave half][phase 1..4][load segment + barrier + fragment wait, MFMA segment, closing barrier] + k-tile count + epilogue cycles
+__device__ unsigned long long m2f_p8_dbg[64];
+#define P8_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
+#define P8_ACC(p) do { tacc[p][0] += ts1 - ts0; tacc[p][1] += ts2 - ts1; tacc[p][2] += ts3 - ts2; if ((p) == 3) ++tk; } while (0)
+#else
+#define P8_STAMP(v) do { (void)sizeof(v); } while (0)
+#define P8_ACC(p) do {} while (0)
+#endif
+
+// EPI: 1 = plain fp32 result (the weight-gradient table: + bias-gradient row sums, ReLU on either operand's fragments),
+//      2 = text-encoder launches: bias, ReLU / GELU, residual, fp32 result unless GF_NO_F32, bf16 shadow
+template <bool RC, bool TABLE, int EPI>
+__global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
+    using C = P8Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;       // LDS byte address of the operand buffers
+    static_assert(offsetof(GemmBatch, count) >= 2880 - 256 && sizeof(GemmBatch) + 64 <= 2880 - 256 + 512, "kernarg warm-up ranges");
+    if constexpr (TABLE) m2f_kernarg_warm<0, 8, 2880 - 256>();
+    else m2f_kernarg_warm<0, 24, 2880 - 256>();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, g = lane >> 4;
+    const int grid = TABLE ? 1 : (int)gridDim.x;
+    typedef const __attribute__((address_space(4))) int* c_i32p;
+    const int total = TABLE ? *((c_i32p)(gb.wg_begin) + blockIdx.x + 1) : gb.total_tiles;
+    const int first = TABLE ? *((c_i32p)(gb.wg_begin) + blockIdx.x) : ring_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (first >= total) return;                                   // (uniform over the workgroup)
+
+    // ------------------------------------------------ prefetch stream ------------------------------------------------
+    int s_idx = first, s_kleft = 0;
+    unsigned s_kA = 0, s_kB = 0, s_stepA = 0, s_stepB = 0, s_halfA = 0, s_halfB = 0, vA[2], vB[2];
+    ring_u32x4 ra, rb;
+    auto cursor_open = [&]() {
+        if (s_idx >= total) {                                      // past the end of the list: every piece is range-checked to zeros
+            ra = p8_rsrc(nullptr, 0); rb = ra; s_kleft = 0x7fffffff;
+            vA[0] = vA[1] = vB[0] = vB[1] = 0; s_kA = s_kB = s_stepA = s_stepB = s_halfA = s_halfB = 0;
+            return;
+        }
+        const P8Desc D = p8_desc<TABLE>(gb, s_idx);
+        const int K = D.K, lda = D.lda, ldb = D.ldb;
+        s_kleft = (K + C::BK - 1) / C::BK;
+        s_kA = s_kB = 0;
+        if constexpr (RC) {
+            // k-major image: 64 k-rows of 128 features (256 bytes); a 1 KiB piece = 4 k-rows; the 16-byte chunk stored at position p
+            // of k-row q is source chunk p ^ (4 (q & 3) | 2 ((q >> 3) & 1)): the eight (k-row, lane-group) combinations of one half of a
+            // transposing fragment read (ds_read_b64_tr_b16 for the 16x16x32 operand: k-rows 8 g + 0..3 of groups g, g + 1) fall on
+            // eight disjoint 32-byte bank ranges
+            const int kr = lane >> 4, p16 = lane & 15;
+            {   // (the wave's second piece = 4 k-rows further down, same swizzle: q & 3 and (q >> 3) & 1 do not change)
+                const int q = 8 * wave + kr;
+                const int sw = p16 ^ (4 * (q & 3) | 2 * ((q >> 3) & 1));
+                vA[0] = (unsigned)(q * lda + D.m0 + 8 * sw) * 2u; vA[1] = (unsigned)(4 * lda) * 2u;       // [1]: uniform
+                vB[0] = (unsigned)(q * ldb + D.n0 + 8 * sw) * 2u; vB[1] = (unsigned)(4 * ldb) * 2u;
+            }
+            s_stepA = (unsigned)(C::BK * lda) * 2u; s_stepB = (unsigned)(C::BK * ldb) * 2u;
+            s_halfA = 256u; s_halfB = 256u;
+            ra = p8_rsrc(D.aq, (unsigned)K * (unsigned)lda * 2u); rb = p8_rsrc(D.bq, (unsigned)K * (unsigned)ldb * 2u);
+        } else {
+            // row-major image of gemm_ring.h: 128-byte rows, chunk c of row r at position c ^ ((r >> 1) & 7); a piece = 8 rows
+            const int lrow = lane >> 3, pos = lane & 7;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (2 * wave + j) * 8 + lrow;
+                const int sw = pos ^ ((r >> 1) & 7);
+                vA[j] = (unsigned)((D.m0 + r) * lda + 8 * sw) * 2u;
+                vB[j] = (unsigned)((D.n0 + r) * ldb + 8 * sw) * 2u;
+            }
+            s_stepA = s_stepB = (unsigned)C::BK * 2u;
+            s_halfA = (unsigned)(128 * lda) * 2u; s_halfB = (unsigned)(128 * ldb) * 2u;
+            ra = p8_rsrc(D.aq, (unsigned)D.M * (unsigned)lda * 2u); rb = p8_rsrc(D.bq, (unsigned)D.N * (unsigned)ldb * 2u);
+        }
+    };
+    // one half-tile: kind 0 = A0, 1 = A1, 2 = B0, 3 = B1 of the cursor's k-tile into buffer X; A1 closes the k-tile
+    auto stage = [&](auto kind_tag, int x) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        const unsigned dst = lds0 + (unsigned)(x * C::BUF + KIND * C::HALF + wave * 2048);
+        if constexpr (KIND < 2) {
+            const unsigned add = s_kA + (KIND == 1 ? s_halfA : 0u);
+            p8_dma16(ra, dst, vA[0] + add);
+            p8_dma16(ra, dst + 1024u, RC ? vA[0] + (add + vA[1]) : vA[1] + add);
+        } else {
+            const unsigned add = s_kB + (KIND == 3 ? s_halfB : 0u);
+            p8_dma16(rb, dst, vB[0] + add);
+            p8_dma16(rb, dst + 1024u, RC ? vB[0] + (add + vB[1]) : vB[1] + add);
+        }
+    };
+    // A1 closes the cursor's k-tile.  The step to the next one - with, at the end of an output tile, the scalar loads and address arithmetic
+    // of the next tile's descriptor - is taken at the head of phase 1, where only the accumulators are live (inside phase 4, with every
+    // fragment register live as well, the branch sent 130 registers to scratch)
+    auto cursor_advance = [&]() {
+        s_kA += s_stepA; s_kB += s_stepB;
+        if (--s_kleft == 0) { s_idx += grid; cursor_open(); }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ------------------------------------------------ fragment addresses ------------------------------------------------
+    // KC: lane -> row lr of a 16-row tile, 16-byte chunk 4 s + g of its 128-byte row (k-step s), stored at chunk ^ ((row >> 1) & 7)
+    // RC: lane 4 qq + pp of group g -> k-row 32 s + 8 g + qq (+ 4: second read), features f0 + 4 pp .. + 3; lane i receives feature f0 + i
+    int offA[4], offB[2];          // KC: [0], [1] = k-step 0 / 1 (row tile i / j adds 2048); RC: per row tile (k-step adds 8192)
+    if constexpr (RC) {
+        const int qq = lr >> 2, pp = lr & 3, sw = 4 * qq | 2 * (g & 1);
+        const int base = (8 * g + qq) * 256 + 8 * (pp & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offA[i] = base + (((8 * wr + 2 * i + (pp >> 1)) ^ sw) << 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) offB[j] = base + (((4 * wc + 2 * j + (pp >> 1)) ^ sw) << 4);
+    } else {
+        const int x = (lr >> 1) & 7;
+        const int f0 = (g ^ x) << 4, f1 = ((4 + g) ^ x) << 4;
+        offA[0] = (wr * 64 + lr) * 128 + f0; offA[1] = (wr * 64 + lr) * 128 + f1; offA[2] = offA[3] = 0;
+        offB[0] = (wc * 32 + lr) * 128 + f0; offB[1] = (wc * 32 + lr) * 128 + f1;
+    }
+    auto frag = [&](const char* half, int off_row_tile, int s, int kc_off0, int kc_off1) -> bf16x8 {
+        if constexpr (RC) {
+            const char* q = half + off_row_tile + s * 8192;
+            const ring_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(q)));
+            const ring_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(q + 1024)));
+            const ring_s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, r);
+        } else {
+            return *reinterpret_cast<const bf16x8*>(half + (s ? kc_off1 : kc_off0) + off_row_tile);
+        }
+    };
+    bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+    // (the buffer offset is a run-time value on purpose: as a constant every fragment address of either buffer is loop-invariant, gets
+    //  hoisted out of the k-loop and the kernel spills hundreds of registers - whose reloads would share the hand-counted vmcnt)
+    auto read_a = [&](int xo, int ah) {
+        const char* half = smem + xo + ah * C::HALF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) af[i][s] = RC ? frag(half, offA[i], s, 0, 0) : frag(half, i * 2048, s, offA[0], offA[1]);
+    };
+    auto read_b = [&](int xo, int bh, bf16x8 (&dst)[2][2]) {
+        const char* half = smem + xo + (2 + bh) * C::HALF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dst[j][s] = RC ? frag(half, offB[j], s, 0, 0) : frag(half, j * 2048, s, offB[0], offB[1]);
+    };
+
+    // ------------------------------------------------ prologue ------------------------------------------------
+    // Skew.  Every tile of a launch takes the same time, so workgroups that start together reach their epilogues together: 256 CUs x
+    // 256 KiB of result in one burst (measured: 25k of a tile's 90k cycles at K = 1,024 went into the stores and the wait for them -
+    // the chip's HBM write rate - with the MFMA pipes idle; profiles/r04_p8_phase_totals_v1.txt).  Workgroups whose list is
+    // shorter than the longest (`gb.p8_max_tiles`) can start late for free: they wait q / 4 of a tile time, q = (workgroup / 8) mod 4,
+    // so that at most about a quarter of the chip stores at any time.  gb.p8_skew = estimated cycles per k-tile (0 = off);
+    // bit 30 set: skew every workgroup, slack or not.
+    if (gb.p8_skew) {
+        const int mine = TABLE ? total - first : (total - first + grid - 1) / grid;
+        const int q = ((int)blockIdx.x >> 3) & 3;
+        if (q && (mine < gb.p8_max_tiles || (gb.p8_skew & 0x40000000))) {
+            const P8Desc D0 = p8_desc<TABLE>(gb, first);
+            const unsigned long long wait = (unsigned long long)((D0.K + C::BK - 1) / C::BK) * (unsigned)(gb.p8_skew & 0xFFFFF) * (unsigned)q / 4u;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    cursor_open();
+    stage(I2{}, 0); stage(I0{}, 0); stage(I3{}, 0); stage(I1{}, 0); cursor_advance();               // k-tile 0 -> buffer 0
+    stage(I2{}, 1); stage(I0{}, 1); stage(I3{}, 1); stage(I1{}, 1);                                  // k-tile 1 -> buffer 1 (advance: head of phase 1)
+    ring_wait_vm<8>();
+    __builtin_amdgcn_s_barrier();                                                     // k-tile 0 is in LDS, for every wave
+    if (wr == 1) __builtin_amdgcn_s_barrier();                                        // the lower half runs one barrier behind
+
+    // ------------------------------------------------ tiles ------------------------------------------------
+    int par = 0;                                                                       // buffer of the next k-tile to multiply
+#ifdef P8_TIMING
+    unsigned long long tacc[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, tk = 0, tep = 0;
+#endif
+    int ep_relax = 0;                                  // vector-memory instructions the LAST epilogue is known to have issued (0, 32 or >= 57)
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3;
+#pragma unroll 1
+    for (int bpos = first; bpos < total; bpos += grid) {
+        const P8Desc H = p8_desc<TABLE>(gb, bpos);
+        // (the table lives in device memory: its fields come through the constant address space = scalar loads; a plain reference is
+        //  read with VECTOR loads, whose wait would drain the prefetch stream once per tile)
+        typedef const __attribute__((address_space(4))) GemmProblem* c_probp;
+        const auto& P = *(TABLE ? (c_probp)(gb.table) + H.pi : (c_probp)(const GemmProblem*)&gb.pr[H.pi]);
+        const int m0 = H.m0, n0 = H.n0, nk = (H.K + C::BK - 1) / C::BK;
+        const bool reluA = false, reluB = H.flags & GF_RELU_B;
+        float* bias_grad = EPI == 1 ? P.bias_grad : nullptr;
+        const bool bgrad = EPI == 1 && RC && bias_grad && n0 == 0 && wc == 0;      // wave-uniform
+        float bsum[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bsum[a][i] = 0.f;
+        f32x4 acc[2][2][4][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // epilogue fields before the k-loop (scalar loads from a cold line cost the tile its MFMA pipe when read after it)
+        float* __restrict__ Cp = P.c;
+        const int ldc = P.ldc, Mm = H.M, Nn = H.N;
+        const float* __restrict__ bias = EPI == 2 ? P.bias : nullptr;
+        const float* __restrict__ res = EPI == 2 ? P.res : nullptr;
+        const int ldres = P.ldres;
+        uint16_t* __restrict__ C16 = EPI == 2 && !(P.flags & GF_NO_BF16) ? reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c)) : nullptr;
+        const bool relu_out = P.flags & GF_RELU_OUT, gelu = P.flags & GF_GELU_OUT, no32 = EPI == 2 && (P.flags & GF_NO_F32) && C16;
+
+        auto quad = [&](auto a_tag, auto b_tag, const bf16x8 (&bb)[2][2]) {
+            constexpr int AH = decltype(a_tag)::value, BH = decltype(b_tag)::value;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)         // operands swapped: the lane then holds 4 consecutive COLUMNS of row lr (16-byte stores)
+                        acc[AH][BH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[j][s], af[i][s], acc[AH][BH][i][j], 0, 0, 0);
+        };
+        auto bias_sums = [&](int ah) {                  // bias gradient = sum over k of A's rows (before any ReLU on A)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const ring_u32x4 w = __builtin_bit_cast(ring_u32x4, af[i][s]);
+                    bsum[ah][i] = ring_bf16x2_sum(w.w, ring_bf16x2_sum(w.z, ring_bf16x2_sum(w.y, ring_bf16x2_sum(w.x, bsum[ah][i]))));
+                }
+        };
+        const uint32_t floorA = reluA ? 0u : 0x80008000u, floorB = reluB ? 0u : 0x80008000u;
+        auto relu_a = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) af[i][s] = p8_floor8(af[i][s], floorA);
+        };
+        auto relu_b = [&](bf16x8 (&bb)[2][2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bb[j][s] = p8_floor8(bb[j][s], floorB);
+        };
+        // one k-tile out of buffer x: four phases.  OPT: 0 = plain, 1 = ReLU floor on the fragments + bias-gradient sums (a copy of the
+        // LOOP, chosen per output tile: branches inside a phase cut it into basic blocks and sent 200 registers to scratch)
+        auto ktile = [&](int x, auto opt_tag, int relax) {
+            constexpr int OPT = decltype(opt_tag)::value;      // bit 0: bias-gradient sums, bit 1: ReLU floor on A, bit 2: on B
+            const int xo = x * C::BUF;
+            // ---- phase 1: B part 0 (4 reads), A part 0 (8 reads); no prefetch piece (the phase with the most reads) ----
+            P8_STAMP(ts0);
+            cursor_advance();                             // (the A1 piece issued in the previous phase 4 closed a k-tile)
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(xo, 0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(xo, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the four B reads, issued first, are back: B0 may be re-staged next phase
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts1);
+            if constexpr (OPT & 1) bias_sums(0);
+            if constexpr (OPT & 2) relu_a();
+            if constexpr (OPT & 4) relu_b(bf0);
+            __builtin_amdgcn_s_setprio(1);
+            quad(I0{}, I0{}, bf0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts2);
+            __builtin_amdgcn_s_barrier();
+            P8_STAMP(ts3);
+            P8_ACC(0);
+            // ---- phase 2: B part 1 (4 reads); stage B0 of k-tile + 2 (this buffer) ----
+            P8_STAMP(ts0);
+            read_b(xo, 1, bf1);
+            stage(I2{}, x);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts1);
+            if constexpr (OPT & 4) relu_b(bf1);
+            __builtin_amdgcn_s_setprio(1);
+            quad(I0{}, I1{}, bf1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts2);
+            __builtin_amdgcn_s_barrier();
+            P8_STAMP(ts3);
+            P8_ACC(1);
+            // ---- phase 3: A part 1 (8 reads); stage A0 of k-tile + 2 ----
+            P8_STAMP(ts0);
+            read_a(xo, 1);
+            stage(I0{}, x);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts1);
+            if constexpr (OPT & 1) bias_sums(1);
+            if constexpr (OPT & 2) relu_a();
+            __builtin_amdgcn_s_setprio(1);
+            quad(I1{}, I1{}, bf1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts2);
+            __builtin_amdgcn_s_barrier();
+            P8_STAMP(ts3);
+            P8_ACC(2);
+            // ---- phase 4: no reads; stage B1 of k-tile + 2; the ONE counted wait: everything but the three youngest half-tiles ----
+            P8_STAMP(ts0);
+            stage(I3{}, x);
+            // everything but the three youngest half-tiles has landed - and, in the first k-tile after an epilogue, but the epilogue's stores,
+            // which were issued between A1 of the next k-tile (below) and those three: loads and stores share ONE in-order counter, and
+            // waiting for 256 KiB of stores here would stall the MFMA pipe for thousands of cycles
+            if (relax == 0) ring_wait_vm<6>();
+            else if (relax == 32) ring_wait_vm<38>();
+            else ring_wait_vm<63>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            P8_STAMP(ts1);
+            stage(I1{}, x);                               // A1 of k-tile + 2 (this buffer: its A1 half was last read in phase 3) - closes the cursor's k-tile
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            quad(I1{}, I0{}, bf0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            P8_STAMP(ts2);
+            __builtin_amdgcn_s_barrier();
+            P8_STAMP(ts3);
+            P8_ACC(3);
+        };
+        // (a copy of the LOOP per option set the weight-gradient table uses - plan.hip sets GF_RELU_B only: the FAM layer's
+        //  relu(cat(x, text)) operand - ReLU on A has no copy: the launchers refuse it)
+#define P8_LOOP(MASK) do { _Pragma("unroll 1") for (int kt = 0; kt < nk; ++kt) { ktile(par, std::integral_constant<int, MASK>{}, kt == 0 ? ep_relax : 0); par ^= 1; } } while (0)
+        const int optm = EPI == 1 ? (bgrad ? 1 : 0) | (reluA ? 2 : 0) | (reluB ? 4 : 0) : 0;
+        if (optm == 0) P8_LOOP(0);
+        else if (optm == 1) P8_LOOP(1);
+        else if (optm == 4) P8_LOOP(4);
+        else if (optm == 5) P8_LOOP(5);
+        else P8_LOOP(5);                                  // (ReLU on A is not this form's: the launchers refuse it)
+#undef P8_LOOP
+
+        P8_STAMP(ts0);
+        // ---------------------------------------- epilogue: stores only ----------------------------------------
+        if (bgrad) {                                    // the four lane groups hold four k-slices of row lr
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = bsum[a][i];
+                    t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+                    const int m = m0 + a * 128 + wr * 64 + i * 16 + lr;
+                    if (g == 0 && m < Mm) bias_grad[m] = t;
+                }
+        }
+        const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) &&
+                         (!res || (((ldres & 3) == 0) && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
+                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!C16 || (reinterpret_cast<uintptr_t>(C16) & 7) == 0);
+        const bool whole = vec && m0 + C::BM <= Mm && n0 + C::BN <= Nn;               // block-uniform
+        // one 16-row x 16-column block of the wave: lane -> row lr, columns 4 g .. 4 g + 3
+        auto element = [&](float a, float bv, float rv) {                              // the element order of ring_epilogue
+            if constexpr (EPI != 2) return a;
+            float x = a + bv;
+            x = relu_out ? fmaxf(x, 0.f) : x;
+            if (gelu) x = m2f_gelu<true>(x);
+            return x + rv;
+        };
+        ep_relax = 0;
+        if (whole) {
+            // (what the next tile's first counted wait may leave in flight: exactly these stores; loads the compiler waits for itself)
+            const int n_st = (no32 ? 0 : 32) + ((EPI == 2 && C16) ? 32 : 0);
+            ep_relax = n_st >= 57 ? 57 : n_st == 32 ? 32 : 0;
+            // straight-line stores: no masks, no branches (32 x 16-byte stores per lane; the residual of block b + 1 is requested before
+            // block b is stored - loads and stores share one in-order counter)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (EPI == 2) { if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col); }
+                        f32x4 rv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if constexpr (EPI == 2) {
+                                const int row = m0 + a * 128 + wr * 64 + i * 16 + lr;
+                                if (res) rv[i] = *reinterpret_cast<const f32x4*>(res + (size_t)((uint32_t)(row * ldres + col)));
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = m0 + a * 128 + wr * 64 + i * 16 + lr;
+                            const size_t oc = (size_t)((uint32_t)(row * ldc + col));
+                            f32x4 v = acc[a][b][i][j];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = element(v[e], bv[e], rv[i][e]);
+                            if (!no32) *reinterpret_cast<f32x4*>(Cp + oc) = v;
+                            if constexpr (EPI == 2) {
+                                if (C16) {
+                                    uint2 hh;
+                                    hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
+                                    hh.y = (uint32_t)m2f_bf16_bits(v[2]) | ((uint32_t)m2f_bf16_bits(v[3]) << 16);
+                                    *reinterpret_cast<uint2*>(C16 + oc) = hh;
+                                }
+                            }
+                        }
+                    }
+        } else {
+            // edge tiles / unaligned results: element by element, masked (rare: 300-wide audio features, the [7, d] classifier weight)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = m0 + a * 128 + wr * 64 + i * 16 + lr, col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                            const f32x4 v = acc[a][b][i][j];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool in = row < Mm && col + e < Nn;
+                                const size_t oc = (size_t)((uint32_t)(row * ldc + col + e));
+                                float bvv = 0.f, rvv = 0.f;
+                                if constexpr (EPI == 2) {
+                                    if (bias && in) bvv = bias[col + e];
+                                    if (res && in) rvv = res[(size_t)((uint32_t)(row * ldres + col + e))];
+                                }
+                                const float x = element(v[e], bvv, rvv);
+                                if (in) {
+                                    Cp[oc] = x;                         // (edge tiles keep the fp32 store whatever GF_NO_F32 says, as the ring form does)
+                                    if constexpr (EPI == 2) { if (C16) C16[oc] = m2f_bf16_bits(x); }
+                                }
+                            }
+                        }
+        }
+#ifdef P8_TIMING
+        P8_STAMP(ts1); tep += ts1 - ts0;
+#endif
+    }
+#ifdef P8_TIMING
+    if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) {
+        for (int p = 0; p < 4; ++p) for (int q = 0; q < 3; ++q) m2f_p8_dbg[wr * 16 + p * 3 + q] += tacc[p][q];
+        m2f_p8_dbg[wr * 16 + 12] += tk; m2f_p8_dbg[wr * 16 + 13] += tep;
+    }
+#endif
+    // the stream ran past the end of the list: its last (zero-filling) pieces must not outlive the workgroup's LDS allocation
+    ring_wait_vm<0>();
+    if (wr == 0) __builtin_amdgcn_s_barrier();                                        // the upper half catches up with the lower one
+}
+
+template <bool RC, bool TABLE, int EPI>
+hipError_t launch_p8_grid(const GemmBatch& hb, int tiles, hipStream_t stream) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    auto kern = m2f_gemm_p8_kernel<RC, TABLE, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8Cfg::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    ++m2f_g_ring_launches;
+    if constexpr (TABLE) {
+        if (!hb.tile_rec || !hb.wg_begin || hb.wg_count < 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(kern, dim3(hb.wg_count), dim3(512), P8Cfg::LDS, stream, hb);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), P8Cfg::LDS, stream, hb);
+    return hipGetLastError();
+}
+
+// grouped launch (problems in the kernel arguments): tile order m fastest inside a problem, workgroups walk remap(b), + grid, ...
+template <bool RC, int EPI>
+hipError_t launch_p8_grouped(GemmBatch& gb, hipStream_t stream) {
+    int t = 0;
+    for (int i = 0; i < gb.count; ++i) {
+        GemmProblem& p = gb.pr[i];
+        p.splitk = 1; p.slab_begin = 0; p.cnt_begin = 0;
+        p.tile_begin = t;
+        p.tiles_n = m2f_cdiv(p.N, P8Cfg::BN);
+        t += m2f_cdiv(p.M, P8Cfg::BM) * p.tiles_n;
+    }
+    if (t == 0) return hipSuccess;
+    GemmBatch hb = gb;
+    for (int i = 0; i < M2F_GEMM_MAX_PROBLEMS; ++i) {
+        hb.tb[i] = i < gb.count ? gb.pr[i].tile_begin : 0x7fffffff;
+        GemmHot& h = hb.hot[i];
+        memset(&h, 0, sizeof(h));
+        if (i >= gb.count) continue;
+        const GemmProblem& p = gb.pr[i];
+        h.aq[0] = p.a.q[0]; h.aq[1] = p.a.q[1]; h.bq[0] = p.b.q[0]; h.bq[1] = p.b.q[1];
+        h.M = p.M; h.N = p.N; h.k[0] = p.a.k[0]; h.k[1] = p.a.k[1];
+        h.ldaq[0] = p.a.ldq[0]; h.ldaq[1] = p.a.ldq[1]; h.ldbq[0] = p.b.ldq[0]; h.ldbq[1] = p.b.ldq[1];
+        h.flags = p.flags; h.tile_begin = p.tile_begin; h.has_bias_grad = 0;
+    }
+    hb.total_tiles = t;
+    {
+        int dev = 0, n_cu = 256; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        const int g = t < n_cu ? t : n_cu;
+        hb.p8_max_tiles = (t + g - 1) / g;
+    }
+    return launch_p8_grid<RC, false, EPI>(hb, t, stream);
+}
+
+}  // namespace

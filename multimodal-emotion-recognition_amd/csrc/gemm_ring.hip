@@ -14,6 +14,7 @@ hipError_t m2f_ring_launch_256x128(GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_table_128x128(const GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_table_rc_128x128(const GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_ring_launch_table_rc_256x128(const GemmBatch& gb, hipStream_t stream);
+hipError_t m2f_p8_launch_table_rc(const GemmBatch& gb, hipStream_t stream);          // gemm_p8.hip: 256 x 256 tiles, eight-phase schedule
 
 // can this forward-form launch run as the ring form?  (no GELU / FP8 / B-side ReLU epilogue variants there; 32-bit byte
 // offsets into every operand)
@@ -49,6 +50,7 @@ hipError_t m2f_launch_gemm_ring(GemmBatch& gb, int bm, int bn, hipStream_t strea
 }
 
 hipError_t m2f_launch_gemm_ring_table(const GemmBatch& gb, hipStream_t stream) {
+    if (gb.table_tile == 132) return m2f_p8_launch_table_rc(gb, stream);
     if (gb.table_tile == 131) return m2f_ring_launch_table_rc_256x128(gb, stream);
     return gb.table_tile == 130 ? m2f_ring_launch_table_rc_128x128(gb, stream) : m2f_ring_launch_table_128x128(gb, stream);
 }

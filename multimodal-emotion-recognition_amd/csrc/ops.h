@@ -105,6 +105,9 @@ struct GemmBatch {
     const uint32_t* tile_rec;
     const int* wg_begin;
     int wg_count;
+    // eight-phase form (gemm_p8.h): start skew - estimated cycles per k-tile (0 = off; bit 30: also workgroups without slack) and the
+    // longest tile list of any workgroup of the launch
+    int p8_skew, p8_max_tiles;
 };
 #define M2F_SPLITK_MAX_TILES 512
 
@@ -115,6 +118,10 @@ bool m2f_gemm_ring_ok(const GemmBatch& gb);
 bool m2f_gemm_ring256_ok(const GemmBatch& gb);       // 256x128 tiles: bias / ReLU / GELU / residual epilogues only
 hipError_t m2f_launch_gemm_ring(GemmBatch& gb, int bm, int bn, hipStream_t stream);
 hipError_t m2f_launch_gemm_ring_table(const GemmBatch& gb, hipStream_t stream);
+// eight-phase 256x256 form (gemm_p8.h): forward-form launches with the 256x128 ring form's epilogue set, single segment, k % 64 == 0
+bool m2f_gemm_p8_ok(const GemmBatch& gb);
+hipError_t m2f_p8_launch_kc(GemmBatch& gb, hipStream_t stream);
+hipError_t m2f_p8_launch_table_rc(const GemmBatch& gb, hipStream_t stream);
 
 // Launches one grouped GEMM. Returns hipSuccess or the launch error. `tile` = 0 (auto), 64 or 128.
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream);
@@ -127,6 +134,7 @@ hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream);
 #ifdef __cplusplus
 #include <vector>
 int m2f_gemm_table_layout(std::vector<GemmProblem>& prs, int tile, std::vector<uint16_t>& tile_prob, bool operand_options = false);
+bool m2f_gemm_p8_table_ok(const std::vector<GemmProblem>& prs);      // table form of gemm_p8.h: no ReLU on A, single segment
 // Per-workgroup tile lists of the ring table forms (tile_m x tile_n tiles: 128x128, 256x128, 256x256) for a grid of n_wg workgroups (workgroup b runs on XCD
 // b % 8 under round-robin placement - speed only).  walk = 0: the order of m2f_gemm_table_layout (every round spreads 256
 // consecutive tiles - usually of ONE problem - over all eight XCDs, so each L2 pulls its own copy of that problem's

@@ -19,7 +19,7 @@
 #include "ops.h"
 
 #ifndef M2F_TABLE_TILE_DEFAULT
-#define M2F_TABLE_TILE_DEFAULT 131      // weight-gradient table launch: see build_plan (M2F_TABLE_TILE)
+#define M2F_TABLE_TILE_DEFAULT 132      // weight-gradient table launch: see build_plan (M2F_TABLE_TILE); 132 = 256 x 256 tiles, eight-phase schedule (round 4)
 #endif
 
 #include <algorithm>
@@ -1080,8 +1080,8 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // tiles, 19.5 M with 256x128; 361 -> 290 us, profiles/r03_*).
     const char* tt_env = getenv("M2F_TABLE_TILE");
     const int tt = tt_env ? atoi(tt_env) : 0;
-    const int table_tile = (tt == 64 || tt == 128 || (tt >= 129 && tt <= 131) || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
-    const bool table_rc = table_tile == 130 || table_tile == 131;          // 131: 256 x 128 tiles
+    int table_tile = (tt == 64 || tt == 128 || (tt >= 129 && tt <= 132) || tt == 256) ? tt : M2F_TABLE_TILE_DEFAULT;
+    const bool table_rc = table_tile >= 130 && table_tile <= 132;          // 131: 256 x 128 tiles; 132: 256 x 256 tiles on the eight-phase schedule (gemm_p8.h)
     // (256 x 256 tiles - eight waves that all load and multiply, no producer waves: the accumulators fill the register file -
     //  were built and measured SLOWER, 342 vs 296 us: commit c3f1730)
     if (table_ok && table_rc) {
@@ -1169,14 +1169,15 @@ int build_plan(m2f_plan& P, char* ws_base) {
     // Tile choice, measured: 256x128 register-staged tiles beat 128x128 ones on the transposed copies (a quarter fewer operand
     // bytes through L1: 145 vs 183 us at C2) and also the ring form on the same copies (129: C3 step 3.707 vs 3.655 ms - this
     // launch keeps all 256 CUs streaming at once and is bound by what the L2s can pull together, so bytes per FLOP decide).
-    const int walk_m = table_tile == 131 ? 256 : 128, walk_n = 128;
-    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : (table_tile == 131 ? 256 : table_tile), tile_prob, table_rc);
+    if (table_tile == 132 && table_ok && !m2f_gemm_p8_table_ok(tprobs)) table_tile = 131;      // (a problem with ReLU on its A operand: the eight-phase form has no loop copy for it)
+    const int walk_m = table_tile >= 131 ? 256 : 128, walk_n = table_tile == 132 ? 256 : 128;
+    if (table_ok) total_tiles = m2f_gemm_table_layout(tprobs, (table_tile == 129 || table_tile == 130) ? 128 : (table_tile >= 131 && table_tile <= 132 ? 256 : table_tile), tile_prob, table_rc);
     if (total_tiles <= 0) table_ok = false;
     // ring table forms: per-workgroup tile lists (m2f_gemm_table_walk).  M2F_TABLE_WALK=0 (read when a plan is built) keeps the
     // order of the tile list; default 1 = every XCD walks its own problems in 8 x 4 super-tiles
     std::vector<uint32_t> tile_rec;
     std::vector<int> wg_begin;
-    const bool table_ring = table_tile >= 129 && table_tile <= 131;
+    const bool table_ring = table_tile >= 129 && table_tile <= 132;
     int wg_count = 0;
     if (table_ok && table_ring) {
         const char* walk_env = getenv("M2F_TABLE_WALK");
@@ -1233,11 +1234,14 @@ int build_plan(m2f_plan& P, char* ws_base) {
             memset(&P.wg_tab, 0, sizeof(P.wg_tab));
             P.wg_tab.table = d_table; P.wg_tab.tile_prob = d_tile_prob; P.wg_tab.total_tiles = total_tiles; P.wg_tab.table_tile = table_tile;
             P.wg_tab.tile_rec = d_tile_rec; P.wg_tab.wg_begin = d_wg_begin; P.wg_tab.wg_count = wg_count;
+            auto longest = [](const std::vector<int>& beg) { int m = 0; for (size_t w = 0; w + 1 < beg.size(); ++w) m = std::max(m, beg[w + 1] - beg[w]); return m; };
+            P.wg_tab.p8_max_tiles = longest(wg_begin);
             P.wg_tab.rng = P.rng; P.wg_tab.drop_thresh = P.drop_thresh; P.wg_tab.drop_scale = P.drop_scale;
             for (int part = 0; part < 2 && split; ++part) {
                 P.wg_tab_part[part] = P.wg_tab;
                 P.wg_tab_part[part].tile_rec = d_part_rec[part]; P.wg_tab_part[part].wg_begin = d_part_begin[part];
                 P.wg_tab_part[part].wg_count = part_wg[part]; P.wg_tab_part[part].total_tiles = (int)part_rec[part].size();
+                P.wg_tab_part[part].p8_max_tiles = longest(part_begin[part]);
             }
             // the fusion stack's (else the classifier's) first parameter: everything from there on is complete after part 0
             P.split_ok = split;

@@ -105,6 +105,8 @@ SIGNATURES = {
                                   c_int, c_void_p, c_int, c_uint32, c_float, c_void_p, c_void_p]),
     "m2f_attention_probs_elems": (c_int64, [c_int, c_int, c_int]),
     "m2f_set_shadow_map": (c_int, [c_void_p, c_void_p, c_int64]),
+    "m2f_gemm_p8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                            c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "m2f_gemm_fp8": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
                              c_int, c_int, c_void_p, c_float, c_void_p]),
     "m2f_quantize_fp8": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

@@ -212,14 +212,17 @@ def test_bf16_weight_gradient_paths_agree_and_track_fp32(golden_dir, name, monke
 
 @pytest.mark.parametrize("name,tile", [("c2_slice", "64"), ("c2_slice", "128"), ("c2_slice", "129"), ("c2_slice", "256"),
                                        ("tiny_ragged", "256"), ("tiny_shared_norm", "256"), ("tiny_no_fam", "129"),
-                                       ("c2_slice", "131"), ("c3_slice_l16", "131"), ("tiny_ragged", "131"), ("tiny_odd_heads", "131")])
+                                       ("c2_slice", "131"), ("c3_slice_l16", "131"), ("tiny_ragged", "131"), ("tiny_odd_heads", "131"),
+                                       ("c3_slice_l24", "130"), ("tiny_shared_norm", "131")])
 def test_bf16_weight_gradient_table_tile_variants_agree(golden_dir, name, tile, monkeypatch):
     """The weight-gradient table launch runs by default in the ring form on the row-major bf16 shadows (130: no token-
     transposed copies; the kernel sums the bias gradients from the bf16 operands) and exists as register-staged 64x64,
     128x128 and 256x128 builds and a ring form (129) on token-transposed copies, whose transposing launch sums the bias
     gradients in fp32 (M2F_TABLE_TILE, read when a plan is built).  Same operands and k order for the weights: they agree
     to fp32 summation noise; the bias gradients to the bf16 rounding of their summands.  131 = the row-major ring form with
-    256 x 128 tiles (two 128-feature images per operand row block)."""
+    256 x 128 tiles (two 128-feature images per operand row block).  Round 4: the DEFAULT is 132 = 256 x 256 tiles on the eight-phase
+    schedule (gemm_p8.h, MFMA 16x16x32 instead of 32x32x16: another summation order inside a k-step) - every variant here is compared
+    against it."""
     fx = _load(golden_dir, name)
     cfg, text, audio, key_pad, emotion = _inputs(name, fx)      # the tiny cases: widths below one tile, ragged token counts
     batch = (text, audio, key_pad, emotion)

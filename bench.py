@@ -151,7 +151,7 @@ PARTS = ["encoders", "fusion", "classifier"]
 
 
 def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump="", packed=False,
-                 repeats=1, overlap=False, algorithm="all_reduce"):
+                 repeats=1, overlap=False, algorithm="all_reduce", fused_adam=False):
     cfg, B, L = wl["cfg"], wl["B"], wl["L"]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=dtype, shape_buckets=False).to(device).train()      # the plan IS the workload's (B, L): no bucket padding
@@ -169,10 +169,19 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         # inputs are resident in the plan's staging buffers before the timed region starts
         plan.set_inputs(text, audio, mask, emotion)
 
+        fused_steps = [0]
+
         def one_step():
             # bf16 mode, N = 1: the fused Adam kernel also writes the bf16 parameter shadows, the forward then skips its parameter
             # casts (the engine compares the parameters' version counters: any other write to them brings the casts back)
             plan.params_fresh(eng.shadows_fresh())
+            if fused_adam and world == 1 and opt.prepare_fused(plan):
+                # round 4: the optimizer step INSIDE the step's graph - the weight-gradient launch applies Adam to the elements whose
+                # gradient it holds in registers (dW never reaches memory), one more launch updates biases / LayerNorm parameters
+                plan.step(0.1, False, False, use_graph)
+                opt.finish_fused(plan)
+                fused_steps[0] += 1
+                return
             if split:
                 # N > 1: the step in two parts - the fusion stack's / classifier's gradient bucket (the tail of the flat buffer, final
                 # after part 0) is on the wire while the encoders' backward (part 1) runs; the encoder buckets follow, each bucket's
@@ -312,8 +321,8 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         "config": {"workload": wl["name"] + (" [MELD-like ragged lengths, valid utterances counted]" if ragged else ""),
                    "dialogues_per_gpu": B, "max_utt": L, "global_batch_dialogues": world * B, "valid_utterances": n_valid_all,
                    "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
-                   "step": ("fwd+CE+bwd (1 hipGraph)" if not split else "fwd+CE+bwd in two hipGraphs") +
-                           (f" + {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} grad all-reduce ({stepper.reducer.exchange}" + (", fusion / classifier bucket sent under the encoders' backward)" if split else ")") if world > 1 else "") + " + fused Adam",
+                   "step": (("fwd+CE+bwd+Adam (1 hipGraph: the weight-gradient launch applies the optimizer in its epilogue)" if fused_steps[0] else "fwd+CE+bwd (1 hipGraph)") if not split else "fwd+CE+bwd in two hipGraphs") +
+                           (f" + {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} grad all-reduce ({stepper.reducer.exchange}" + (", fusion / classifier bucket sent under the encoders' backward)" if split else ")") if world > 1 else "") + ("" if fused_steps[0] else " + fused Adam"),
                    "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                    "launches_per_step": plan.num_launches(),
                    "token_rows": plan.T, "plan_shape": [plan.B, plan.L], "packed": bool(plan.packed),
@@ -388,6 +397,11 @@ def main():
     ap.add_argument("--dp-algorithm", default=os.environ.get("M2F_DP_ALGORITHM", "all_reduce"), choices=list(dp.ALGORITHMS),
                     help="N > 1: per bucket one all-reduce, or reduce-scatter + all-gather (SURVEY section 5's direct exchange over the "
                          "fully connected xGMI links)")
+    ap.add_argument("--fused-adam", action="store_true", default=os.environ.get("M2F_FUSED_ADAM", "0") == "1",
+                    help="N = 1, bf16: apply the optimizer in the weight-gradient launch's epilogue (dW never reaches memory; bit-identical "
+                         "parameters).  OFF by default: measured SLOWER at C3 (fused launch 897 us against 243 + 556 us for table launch + "
+                         "optimizer kernel, profiles/r04_dev_fused_adam_ab.txt) - tile-shaped 64-byte-per-row accesses to p / m / v reach "
+                         "4.2 TB/s where the linear optimizer kernel streams 6.0")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 parity mode) leg of the same workload")
     ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
                     help="second single-GPU configuration reported under `secondary` (N = 1 only)")
@@ -426,7 +440,7 @@ def main():
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
                        roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed, repeats=max(1, args.repeats),
-                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm)
+                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm, fused_adam=args.fused_adam)
     if rank == 0:
         out = res
         if world == 1 and args.dtype == "bf16" and not args.no_parity_leg and not args.ragged and not args.packed:

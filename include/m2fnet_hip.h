@@ -251,6 +251,22 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1,
  * pad columns zero).  In bf16 mode a launch whose operands all have one stages from them (half the bytes per CU).
  * splitk_ws / splitk_tickets (nullable): scratch for in-launch split-K of launches too small to fill the chip:
  * splitk_max_tiles * 4 * 64*64 floats and splitk_max_tiles ZEROED uint32 tickets (re-armed by the kernel). */
+/* ---- optimizer inside the step (round 4) ----------------------------------------------------------------------
+ * torch.optim.Adam.step (src/train.py:56,231) applied where the weight gradient is born: the weight-gradient launch of a bf16 train
+ * plan (eight-phase table form, M2F_TABLE_TILE=132) updates p / exp_avg / exp_avg_sq and both bf16 parameter shadows of the elements
+ * whose dW it holds in registers, and one launch of the shadow-writing Adam kernel updates everything else (biases, LayerNorm, the
+ * few matrices outside the table) - all inside m2f_step's captured graph.  dW of the table's matrices is NOT written to `grads`.
+ * Same arithmetic as m2f_adam_step_shadowed on the same gradients: bit-identical parameters, moments and shadows.
+ * setup: buffers as for m2f_adam_step_shadowed (params = the plan's parameter buffer, param_shadow = the buffer the plan was created
+ * with); hyper_dev = 8 device floats refreshed by m2f_adam_hyper BEFORE every step (lr, betas, eps, weight decay, step count t >= 1:
+ * lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) change every step and a replayed graph cannot take them as arguments);
+ * grad_scale_ptr (nullable): device scalar the gradients are divided by (m2f_step(normalise = 0)).
+ * m2f_plan_fused_adam(plan, 1 | 0) switches the form of the NEXT m2f_step (re-captures the graph on a change). */
+int m2f_plan_fused_adam_setup(m2f_plan* plan, float* params, float* exp_avg, float* exp_avg_sq, uint16_t* param_shadow,
+                              const float* hyper_dev, const float* grad_scale_ptr);
+int m2f_plan_fused_adam(m2f_plan* plan, int on);
+int m2f_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, m2f_stream_t stream);
+
 /* The 256x256-tile bf16 GEMM on the eight-phase schedule (csrc/gemm_p8.h; round 4), bf16 operands handed over directly - the kernel
  * the weight-gradient table launch (rc = 1) and the text encoder's launches (rc = 0) run, for kernel-level tests and measurements.
  *   rc = 0: C[M,N] = act(A[M,K] B[N,K]^T + bias) + res   (nn.Linear forward: src/feature_extractors/text/model.py:16-21's encoder

@@ -32,6 +32,7 @@
 
 namespace {
 
+#define P8_ADAM_T_BYTES 2304                          // per wave: the W^T image of the Adam epilogue, 16 x 136 bytes (+ pad)
 struct P8Cfg {
     static constexpr int BM = 256, BN = 256, BK = 64;
     static constexpr int HALF = 128 * BK * 2;          // one operand half-tile: 128 rows (KC) or features (RC) x 64 k, 16 KiB
@@ -106,6 +107,24 @@ __device__ unsigned long long m2f_p8_dbg[64];
 #define P8_ACC(p) do {} while (0)
 #endif
 
+// torch.optim.Adam's update of four consecutive elements: the arithmetic of rowops.hip::adam4, contractions spelled out the same way
+// (every optimizer kernel must produce the same bits: tests/test_shared_shadows_gpu.py compares the trajectories)
+__device__ __forceinline__ void p8_adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float gs, float lr_bc1, float beta1,
+                                         float beta2, float eps, float wd, float inv_sqrt_bc2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gr = __builtin_fmaf(gg[e], gs, wd * pp[e]);     // coupled L2 (Adam, not AdamW)
+        mm[e] = __builtin_fmaf(beta1, mm[e], (1.f - beta1) * gr);
+        vv[e] = __builtin_fmaf(beta2, vv[e], ((1.f - beta2) * gr) * gr);
+        const float denom = __builtin_fmaf(sqrtf(vv[e]), inv_sqrt_bc2, eps);
+        pp[e] = __builtin_fmaf(-lr_bc1, mm[e] / denom, pp[e]);
+    }
+}
+
+// EPI: 3 = the weight-gradient table with the OPTIMIZER in its epilogue: the accumulators are the gradient; the lane that holds four
+//          consecutive elements of dW loads p, m, v of those elements, applies Adam, stores p, m, v and both bf16 parameter shadows
+//          (W 8 bytes; W^T four 2-byte stores, 16 consecutive rows per 16 lanes) - dW never reaches memory (-8 bytes per parameter
+//          and step, and the HBM-bound optimizer streams while other workgroups multiply)
 // EPI: 1 = plain fp32 result (the weight-gradient table: + bias-gradient row sums, ReLU on either operand's fragments),
 //      2 = text-encoder launches: bias, ReLU / GELU, residual, fp32 result unless GF_NO_F32, bf16 shadow
 template <bool RC, bool TABLE, int EPI>
@@ -129,9 +148,20 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
 
     // ------------------------------------------------ prefetch stream ------------------------------------------------
     int s_idx = first, s_kleft = 0;
+    // EPI 3 (optimizer in the epilogue): the stream ENDS with its output tile - the epilogue needs the operand buffers as its own
+    // staging ring - so pieces issued past the tile's last k-tile (the schedule keeps issuing them: the counted waits count them) are
+    // range-checked to zeros AND redirected into a 2 KiB dump area behind the operand buffers (the wave's W^T image, unused until then)
+    constexpr bool PER_TILE = EPI == 3;
+    unsigned s_dump = 0;                                           // 0 = normal destinations
     unsigned s_kA = 0, s_kB = 0, s_stepA = 0, s_stepB = 0, s_halfA = 0, s_halfB = 0, vA[2], vB[2];
     ring_u32x4 ra, rb;
+    auto cursor_close = [&]() {
+        ra = p8_rsrc(nullptr, 0); rb = ra; s_kleft = 0x7fffffff;
+        vA[0] = vA[1] = vB[0] = vB[1] = 0; s_kA = s_kB = s_stepA = s_stepB = s_halfA = s_halfB = 0;
+        s_dump = lds0 + (unsigned)(C::LDS + wave * P8_ADAM_T_BYTES);
+    };
     auto cursor_open = [&]() {
+        s_dump = 0;
         if (s_idx >= total) {                                      // past the end of the list: every piece is range-checked to zeros
             ra = p8_rsrc(nullptr, 0); rb = ra; s_kleft = 0x7fffffff;
             vA[0] = vA[1] = vB[0] = vB[1] = 0; s_kA = s_kB = s_stepA = s_stepB = s_halfA = s_halfB = 0;
@@ -174,7 +204,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
     // one half-tile: kind 0 = A0, 1 = A1, 2 = B0, 3 = B1 of the cursor's k-tile into buffer X; A1 closes the k-tile
     auto stage = [&](auto kind_tag, int x) {
         constexpr int KIND = decltype(kind_tag)::value;
-        const unsigned dst = lds0 + (unsigned)(x * C::BUF + KIND * C::HALF + wave * 2048);
+        const unsigned dst = (PER_TILE && s_dump) ? s_dump : lds0 + (unsigned)(x * C::BUF + KIND * C::HALF + wave * 2048);
         if constexpr (KIND < 2) {
             const unsigned add = s_kA + (KIND == 1 ? s_halfA : 0u);
             p8_dma16(ra, dst, vA[0] + add);
@@ -190,7 +220,10 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
     // fragment register live as well, the branch sent 130 registers to scratch)
     auto cursor_advance = [&]() {
         s_kA += s_stepA; s_kB += s_stepB;
-        if (--s_kleft == 0) { s_idx += grid; cursor_open(); }
+        if (--s_kleft == 0) {
+            if constexpr (PER_TILE) cursor_close();
+            else { s_idx += grid; cursor_open(); }
+        }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -258,12 +291,15 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
             while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
         }
     }
-    cursor_open();
-    stage(I2{}, 0); stage(I0{}, 0); stage(I3{}, 0); stage(I1{}, 0); cursor_advance();               // k-tile 0 -> buffer 0
-    stage(I2{}, 1); stage(I0{}, 1); stage(I3{}, 1); stage(I1{}, 1);                                  // k-tile 1 -> buffer 1 (advance: head of phase 1)
-    ring_wait_vm<8>();
-    __builtin_amdgcn_s_barrier();                                                     // k-tile 0 is in LDS, for every wave
-    if (wr == 1) __builtin_amdgcn_s_barrier();                                        // the lower half runs one barrier behind
+    auto prologue = [&]() {
+        cursor_open();
+        stage(I2{}, 0); stage(I0{}, 0); stage(I3{}, 0); stage(I1{}, 0); cursor_advance();           // k-tile 0 -> buffer 0
+        stage(I2{}, 1); stage(I0{}, 1); stage(I3{}, 1); stage(I1{}, 1);                              // k-tile 1 -> buffer 1 (advance: head of phase 1)
+        ring_wait_vm<8>();
+        __builtin_amdgcn_s_barrier();                                                 // k-tile 0 is in LDS, for every wave
+        if (wr == 1) __builtin_amdgcn_s_barrier();                                    // the lower half runs one barrier behind
+    };
+    if constexpr (!PER_TILE) prologue();
 
     // ------------------------------------------------ tiles ------------------------------------------------
     int par = 0;                                                                       // buffer of the next k-tile to multiply
@@ -275,6 +311,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
     (void)ts0; (void)ts1; (void)ts2; (void)ts3;
 #pragma unroll 1
     for (int bpos = first; bpos < total; bpos += grid) {
+        if constexpr (PER_TILE) { s_idx = bpos; par = 0; prologue(); }
         const P8Desc H = p8_desc<TABLE>(gb, bpos);
         // (the table lives in device memory: its fields come through the constant address space = scalar loads; a plain reference is
         //  read with VECTOR loads, whose wait would drain the prefetch stream once per tile)
@@ -282,8 +319,8 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
         const auto& P = *(TABLE ? (c_probp)(gb.table) + H.pi : (c_probp)(const GemmProblem*)&gb.pr[H.pi]);
         const int m0 = H.m0, n0 = H.n0, nk = (H.K + C::BK - 1) / C::BK;
         const bool reluA = false, reluB = H.flags & GF_RELU_B;
-        float* bias_grad = EPI == 1 ? P.bias_grad : nullptr;
-        const bool bgrad = EPI == 1 && RC && bias_grad && n0 == 0 && wc == 0;      // wave-uniform
+        float* bias_grad = (EPI == 1 || EPI == 3) ? P.bias_grad : nullptr;
+        const bool bgrad = (EPI == 1 || EPI == 3) && RC && bias_grad && n0 == 0 && wc == 0;      // wave-uniform
         float bsum[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -431,7 +468,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
         // (a copy of the LOOP per option set the weight-gradient table uses - plan.hip sets GF_RELU_B only: the FAM layer's
         //  relu(cat(x, text)) operand - ReLU on A has no copy: the launchers refuse it)
 #define P8_LOOP(MASK) do { _Pragma("unroll 1") for (int kt = 0; kt < nk; ++kt) { ktile(par, std::integral_constant<int, MASK>{}, kt == 0 ? ep_relax : 0); par ^= 1; } } while (0)
-        const int optm = EPI == 1 ? (bgrad ? 1 : 0) | (reluA ? 2 : 0) | (reluB ? 4 : 0) : 0;
+        const int optm = (EPI == 1 || EPI == 3) ? (bgrad ? 1 : 0) | (reluA ? 2 : 0) | (reluB ? 4 : 0) : 0;
         if (optm == 0) P8_LOOP(0);
         else if (optm == 1) P8_LOOP(1);
         else if (optm == 4) P8_LOOP(4);
@@ -451,6 +488,132 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                     const int m = m0 + a * 128 + wr * 64 + i * 16 + lr;
                     if (g == 0 && m < Mm) bias_grad[m] = t;
                 }
+        }
+        if constexpr (EPI == 3) {
+            typedef const __attribute__((address_space(4))) M2FAdamFuse* c_adamp;
+            typedef const __attribute__((address_space(4))) float* c_f32p;
+            const auto& AD = *(c_adamp)(gb.adam);
+            const ptrdiff_t doff = Cp - AD.g_base;                                     // this problem's first element in the flat buffers
+            float* __restrict__ Pp = AD.p + doff; float* __restrict__ Mp = AD.m + doff; float* __restrict__ Vp = AD.v + doff;
+            uint16_t* __restrict__ shw = reinterpret_cast<uint16_t*>(const_cast<float*>(P.res));
+            uint16_t* __restrict__ shwt = reinterpret_cast<uint16_t*>(const_cast<float*>(P.gate));
+            const int ldd = P.ldres, ldt = P.ldgate;
+            c_f32p hy = (c_f32p)(AD.hyper);
+            const float lr_bc1 = hy[0], beta1 = hy[1], beta2 = hy[2], eps = hy[3], wd = hy[4], inv_sqrt_bc2 = hy[5];
+            const float gs = AD.gs_ptr ? 1.0f / *((c_f32p)(AD.gs_ptr)) : 1.0f;
+            const bool avec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Pp) & 15) == 0) && ((reinterpret_cast<uintptr_t>(shw) & 7) == 0) && ((ldd & 3) == 0);
+            const bool wt8 = ((reinterpret_cast<uintptr_t>(shwt) & 7) == 0) && ((ldt & 3) == 0), wt16 = ((reinterpret_cast<uintptr_t>(shwt) & 15) == 0) && ((ldt & 7) == 0);
+            const bool awhole = avec && wt8 && m0 + C::BM <= Mm && n0 + C::BN <= Nn;
+            ep_relax = 0;
+            // the stream of this tile has ended (PER_TILE): its last pieces - zeros into the dump area - must have landed, and every wave
+            // must be past its last fragment read, before the operand buffers become the epilogue's staging ring.  The upper half waits one
+            // extra barrier here (the lower half's last closing barrier): from now to the next tile's prologue both halves run aligned.
+            ring_wait_vm<0>();
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+            if (awhole) {
+                // 32 blocks of 16 rows x 16 columns per wave.  p, m, v of a block arrive by LDS-DMA (no staging registers) in a wave-private
+                // ring of FIVE blocks (3 KiB each: 15 of the wave's 16 KiB of the operand buffers), four blocks ahead of the block being
+                // updated: ~128 KiB in flight per CU.  With eight waves per CU and registers for two blocks in flight the epilogue moved
+                // 3.4 TB/s (15 GB/s per CU = 48 KiB in flight / 3 us of loaded latency) and the fused launch was SLOWER than table launch +
+                // optimizer kernel (0.95 vs 0.83 ms at C3).  Lane -> its own 16 bytes of every piece (source = its four elements).
+                // W^T shadow: the four row blocks of a column block go through a wave-private LDS image [16 columns][64 rows] (136-byte
+                // rows) and leave as whole 128-byte rows of W^T.
+                char* tw = smem + C::LDS + wave * P8_ADAM_T_BYTES;
+                const unsigned ring0 = lds0 + (unsigned)(wave * 16384);
+                const char* ringp = smem + wave * 16384 + lane * 16;
+                const ring_u32x4 rp = p8_rsrc(Pp, 0x7FFFFF00u), rm = p8_rsrc(Mp, 0x7FFFFF00u), rv = p8_rsrc(Vp, 0x7FFFFF00u);
+                auto blk = [&](int n, int& a, int& b, int& j, int& i) { a = n >> 4; b = (n >> 3) & 1; j = (n >> 2) & 1; i = n & 3; };
+                auto issue = [&](int n) {
+                    int a, b, j, i; blk(n, a, b, j, i);
+                    const int row = m0 + a * 128 + wr * 64 + i * 16 + lr, col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                    const unsigned vo = (unsigned)(row * ldc + col) * 4u;
+                    const unsigned slot = ring0 + (unsigned)((n % 5) * 3072);
+                    p8_dma16(rp, slot, vo); p8_dma16(rm, slot + 1024u, vo); p8_dma16(rv, slot + 2048u, vo);
+                };
+#pragma unroll
+                for (int n = 0; n < 5; ++n) issue(n);
+#pragma unroll
+                for (int n = 0; n < 32; ++n) {
+                    // block n has landed once at most the operations issued AFTER its three pieces are outstanding: the pieces of the blocks
+                    // ahead (3 each) and the stores of the blocks behind (at least 4 each: p, m, v, W shadow; the W^T stores only add)
+                    constexpr int S4 = 4;
+                    const int ahead = 31 - n < 4 ? 31 - n : 4;
+                    const int allowed = n < 5 ? 3 * (4 - n) + (S4 + 3) * n : S4 * 4 + 3 * ahead;
+                    switch (allowed) {                         // (compile-time after unrolling: one s_waitcnt)
+                        case 12: ring_wait_vm<12>(); break; case 16: ring_wait_vm<16>(); break; case 19: ring_wait_vm<19>(); break;
+                        case 20: ring_wait_vm<20>(); break; case 22: ring_wait_vm<22>(); break; case 24: ring_wait_vm<24>(); break;
+                        case 25: ring_wait_vm<25>(); break; case 28: ring_wait_vm<28>(); break; default: ring_wait_vm<0>(); break;
+                    }
+                    int a, b, j, i; blk(n, a, b, j, i);
+                    const int row = m0 + a * 128 + wr * 64 + i * 16 + lr, col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                    const size_t oc = (size_t)((uint32_t)(row * ldc + col));
+                    const char* sl = ringp + (n % 5) * 3072;
+                    f32x4 pp = *reinterpret_cast<const f32x4*>(sl), mm = *reinterpret_cast<const f32x4*>(sl + 1024), vv = *reinterpret_cast<const f32x4*>(sl + 2048);
+                    p8_adam4(pp, acc[a][b][i][j], mm, vv, gs, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2);
+                    *reinterpret_cast<f32x4*>(Pp + oc) = pp;
+                    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(Mp + oc));
+                    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(Vp + oc));
+                    const uint16_t h0 = m2f_bf16_bits(pp[0]), h1 = m2f_bf16_bits(pp[1]), h2 = m2f_bf16_bits(pp[2]), h3 = m2f_bf16_bits(pp[3]);
+                    uint2 w;
+                    w.x = (uint32_t)h0 | ((uint32_t)h1 << 16); w.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                    *reinterpret_cast<uint2*>(shw + (size_t)((uint32_t)(row * ldd + col))) = w;
+                    uint16_t* tq = reinterpret_cast<uint16_t*>(tw + (4 * g) * 136) + i * 16 + lr;      // image [column 4 g + e][row 16 i + lr]
+                    tq[0] = h0; tq[68] = h1; tq[136] = h2; tq[204] = h3;
+                    // (the slot's three reads are back - their values were just used - before the slot is handed to block n + 5)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (n + 5 < 32) issue(n + 5);
+                    if (i == 3) {                          // a column block's four row blocks are in the image: 16 rows of W^T x 128 bytes
+                        __builtin_amdgcn_wave_barrier();
+                        const int tc = lane >> 2, part = lane & 3;      // lane -> column tc, rows 16 part .. 16 part + 15 (32 bytes)
+                        const uint2* src = reinterpret_cast<const uint2*>(tw + tc * 136 + part * 32);
+                        const uint2 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        const int colT = n0 + b * 128 + wc * 32 + j * 16 + tc, rowT = m0 + a * 128 + wr * 64 + 16 * part;
+                        uint16_t* dst = shwt + (size_t)((uint32_t)(colT * ldt + rowT));
+                        if (wt16) {
+                            *reinterpret_cast<uint4*>(dst) = make_uint4(r0.x, r0.y, r1.x, r1.y);
+                            *reinterpret_cast<uint4*>(dst + 8) = make_uint4(r2.x, r2.y, r3.x, r3.y);
+                        } else {
+                            reinterpret_cast<uint2*>(dst)[0] = r0; reinterpret_cast<uint2*>(dst)[1] = r1;
+                            reinterpret_cast<uint2*>(dst)[2] = r2; reinterpret_cast<uint2*>(dst)[3] = r3;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = m0 + a * 128 + wr * 64 + i * 16 + lr, col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                                f32x4 pp, mm, vv;
+                                bool in[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    in[e] = row < Mm && col + e < Nn;
+                                    const size_t oc = in[e] ? (size_t)((uint32_t)(row * ldc + col + e)) : 0;
+                                    pp[e] = Pp[oc]; mm[e] = Mp[oc]; vv[e] = Vp[oc];
+                                }
+                                p8_adam4(pp, acc[a][b][i][j], mm, vv, gs, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (in[e]) {
+                                        const size_t oc = (size_t)((uint32_t)(row * ldc + col + e));
+                                        Pp[oc] = pp[e]; Mp[oc] = mm[e]; Vp[oc] = vv[e];
+                                        const uint16_t h = m2f_bf16_bits(pp[e]);
+                                        shw[(size_t)((uint32_t)(row * ldd + col + e))] = h;
+                                        shwt[(size_t)((uint32_t)((col + e) * ldt + row))] = h;
+                                    }
+                            }
+            }
+            // every wave is done with its staging ring (and its dump / image area) before the next tile's prologue refills the buffers
+            ring_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            continue;                                      // (next output tile)
         }
         const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) &&
                          (!res || (((ldres & 3) == 0) && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
@@ -548,7 +711,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
 #endif
     // the stream ran past the end of the list: its last (zero-filling) pieces must not outlive the workgroup's LDS allocation
     ring_wait_vm<0>();
-    if (wr == 0) __builtin_amdgcn_s_barrier();                                        // the upper half catches up with the lower one
+    if constexpr (!PER_TILE) { if (wr == 0) __builtin_amdgcn_s_barrier(); }           // the upper half catches up with the lower one
 }
 
 template <bool RC, bool TABLE, int EPI>
@@ -560,19 +723,20 @@ hipError_t launch_p8_grid(const GemmBatch& hb, int tiles, hipStream_t stream) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     auto kern = m2f_gemm_p8_kernel<RC, TABLE, EPI>;
+    constexpr int lds_bytes = P8Cfg::LDS + (EPI == 3 ? 8 * P8_ADAM_T_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8Cfg::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     ++m2f_g_ring_launches;
     if constexpr (TABLE) {
         if (!hb.tile_rec || !hb.wg_begin || hb.wg_count < 1) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(kern, dim3(hb.wg_count), dim3(512), P8Cfg::LDS, stream, hb);
+        hipLaunchKernelGGL(kern, dim3(hb.wg_count), dim3(512), lds_bytes, stream, hb);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), P8Cfg::LDS, stream, hb);
+    hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), lds_bytes, stream, hb);
     return hipGetLastError();
 }
 

@@ -25,6 +25,15 @@ hipError_t m2f_p8_launch_kc(GemmBatch& gb, hipStream_t stream) {
     return launch_p8_grouped<false, 2>(gb, stream);
 }
 
+// the table launch with the optimizer in its epilogue (gb.adam set; every problem carries its shadow pointers in res / gate)
+hipError_t m2f_p8_launch_table_rc_adam(const GemmBatch& gb, hipStream_t stream) {
+    if (!gb.adam) return hipErrorInvalidValue;
+    GemmBatch hb = gb;
+    if (!hb.p8_max_tiles) hb.p8_skew = 0;
+    else if (!hb.p8_skew) hb.p8_skew = p8_skew_env();
+    return launch_p8_grid<true, true, 3>(hb, hb.total_tiles, stream);
+}
+
 bool m2f_gemm_p8_table_ok(const std::vector<GemmProblem>& prs) {
     for (const GemmProblem& p : prs)
         if ((p.flags & GF_RELU_A) || p.a.k[1] || p.b.k[1]) return false;

@@ -108,6 +108,16 @@ struct GemmBatch {
     // eight-phase form (gemm_p8.h): start skew - estimated cycles per k-tile (0 = off; bit 30: also workgroups without slack) and the
     // longest tile list of any workgroup of the launch
     int p8_skew, p8_max_tiles;
+    // eight-phase table form with the optimizer in its epilogue (EPI 3, round 4): the tile that holds a weight gradient in registers
+    // applies torch.optim.Adam's update to its parameter elements - dW never reaches memory.  Device pointer (scalar loads), null = off.
+    // Per problem: res = (float*) bf16 shadow W of the problem's first element, gate = (float*) shadow W^T of it, ldres / ldgate their leading
+    // dimensions (pad8(cols), pad8(rows of the whole tensor)).
+    const struct M2FAdamFuse* adam;
+};
+struct M2FAdamFuse {
+    float* p; const float* g_base; float* m; float* v;      // flat parameter / gradient / moment buffers, same indexing; the problems' c points into g_base
+    const float* hyper;                                     // device: lr / bc1, beta1, beta2, eps, weight_decay, 1 / sqrt(bc2) (m2f_launch_adam_hyper)
+    const float* gs_ptr;                                    // nullable device scalar: gradients are divided by it (global valid-utterance denominator)
 };
 #define M2F_SPLITK_MAX_TILES 512
 
@@ -122,6 +132,7 @@ hipError_t m2f_launch_gemm_ring_table(const GemmBatch& gb, hipStream_t stream);
 bool m2f_gemm_p8_ok(const GemmBatch& gb);
 hipError_t m2f_p8_launch_kc(GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_p8_launch_table_rc(const GemmBatch& gb, hipStream_t stream);
+hipError_t m2f_p8_launch_table_rc_adam(const GemmBatch& gb, hipStream_t stream);     // Adam in the epilogue (gb.adam)
 
 // Launches one grouped GEMM. Returns hipSuccess or the launch error. `tile` = 0 (auto), 64 or 128.
 hipError_t m2f_launch_gemm(GemmBatch& gb, int prec, int layout, int tile, hipStream_t stream);
@@ -314,6 +325,10 @@ hipError_t m2f_launch_adam_shadowed(float* p, const void* g, int g_is_bf16, floa
                                     const int* tile_begin, int n_items, int tile_first, int total_tiles, float lr, float beta1,
                                     float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
                                     hipStream_t stream);
+
+hipError_t m2f_launch_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
+hipError_t m2f_launch_adam_shadowed_dev(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items, const int* tile_begin,
+                                        int n_items, int total_tiles, const float* hyper_dev, const float* grad_scale_ptr, hipStream_t stream);
 
 #ifdef __HIPCC__
 // shadow address of a workspace element, or null (no shadows / pointer outside the workspace, e.g. the gradient buffer)

@@ -267,6 +267,18 @@ struct m2f_plan {
     int n_no_f32 = 0;                    // outputs whose fp32 copy is not written (mark_unread_fp32)
     int64_t split_offset = 0;
     GemmBatch wg_tab_part[2];
+    // Optimizer in the weight-gradient launch's epilogue (round 4; m2f_plan_fused_adam_setup / m2f_plan_fused_adam): the table launch in its
+    // Adam form (gemm_p8.h EPI 3) + ONE launch of the shadow-writing Adam kernel over the tensors the table does not cover (1-D
+    // parameters, weight gradients of wg_rest), both reading their step-dependent factors from device memory so that the captured
+    // graph stays valid from step to step.
+    std::vector<GemmProblem> tprobs_host;        // the table's problems as uploaded (host copy)
+    GemmBatch wg_tab_adam;
+    bool fused_ready = false, fused_on = false;
+    void* fused_dev = nullptr;                   // one hipMalloc: M2FAdamFuse | GemmProblem[] | AdamItem[] | int tile_begin[]
+    float* fz_p = nullptr; float* fz_m = nullptr; float* fz_v = nullptr; uint16_t* fz_sh = nullptr;
+    const float* fz_hyper = nullptr; const float* fz_gs = nullptr;
+    const AdamItem* fz_items = nullptr; const int* fz_tb = nullptr; int fz_n_items = 0, fz_tiles = 0;
+    int g_fused = -1;
     size_t wg_rest_head = 0;             // wg_rest[0, wg_rest_head) belong to part 0
     hipGraphExec_t gexec_part[2] = {nullptr, nullptr};
     float gp_ls[2] = {0.f, 0.f}; int gp_cw[2] = {-1, -1}, gp_norm[2] = {-1, -1}, gp_fresh[2] = {-1, -1};
@@ -279,6 +291,7 @@ struct m2f_plan {
     ~m2f_plan() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
         for (hipGraphExec_t g : gexec_part) if (g) (void)hipGraphExecDestroy(g);
+        if (fused_dev) (void)hipFree(fused_dev);
     }
 };
 
@@ -1215,6 +1228,7 @@ int build_plan(m2f_plan& P, char* ws_base) {
     P.ws_used = bld.ar.off;
     if (table_ok && P.prec == M2F_PREC_BF16 && ws_base != nullptr) {
         bool ok = hipMemcpy(d_table, tprobs.data(), tprobs.size() * sizeof(GemmProblem), hipMemcpyHostToDevice) == hipSuccess;
+        P.tprobs_host = tprobs;
         ok = ok && hipMemcpy(d_tile_prob, tile_prob.data(), tile_prob.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
         if (table_ring) {
             ok = ok && hipMemcpy(d_tile_rec, tile_rec.data(), tile_rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
@@ -1406,7 +1420,8 @@ int do_backward(m2f_plan& P, hipStream_t s) {
         if (P.wg_trans.blocks > 0) M2F_HIP(m2f_launch_transpose_tokens(P.wg_trans, s));
         for (const CastBatch& cb : P.wg_casts) M2F_HIP(m2f_launch_cast(cb, s));
         if (g_prof) { g_prof->end(); g_prof->begin(M2F_LAYOUT_TN, P.wg_flops); }
-        M2F_HIP(m2f_launch_gemm_table(P.wg_tab, s));
+        if (P.fused_on) M2F_HIP(m2f_p8_launch_table_rc_adam(P.wg_tab_adam, s));      // dW stays in registers: Adam in the epilogue
+        else M2F_HIP(m2f_launch_gemm_table(P.wg_tab, s));
         if (g_prof) g_prof->end();
         if (int r = run_launches(P, P.wg_rest, s)) return r;
     } else {
@@ -1415,6 +1430,12 @@ int do_backward(m2f_plan& P, hipStream_t s) {
     for (const LnReduceBatch& rb : P.lnred) {
         if (g_prof) g_prof->begin(9, 0.0);
         M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
+        if (g_prof) g_prof->end();
+    }
+    if (P.fused_on) {                                  // every gradient the table launch did not consume: biases, LayerNorm, wg_rest's matrices
+        if (g_prof) g_prof->begin(10, 0.0);
+        M2F_HIP(m2f_launch_adam_shadowed_dev(P.fz_p, P.grads, P.fz_m, P.fz_v, P.fz_sh, P.fz_items, P.fz_tb, P.fz_n_items, P.fz_tiles,
+                                             P.fz_hyper, P.fz_gs, s));
         if (g_prof) g_prof->end();
     }
     return 0;
@@ -1654,6 +1675,98 @@ int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* gr
                                         weight_decay, step, grad_scale_ptr, stream);
 }
 
+/* Optimizer inside the step (round 4).  See include/m2fnet_hip.h. */
+int m2f_plan_fused_adam_setup(m2f_plan* plan, float* params, float* exp_avg, float* exp_avg_sq, uint16_t* param_shadow,
+                              const float* hyper_dev, const float* grad_scale_ptr) {
+    if (!plan) return fail("m2f_plan_fused_adam_setup: NULL plan (destroyed?)");
+    m2f_plan& P = *plan;
+    P.fused_ready = false; P.fused_on = false;
+    if (!P.train || !P.grads || P.prec != M2F_PREC_BF16 || !P.wg_nt || P.wg_tab.table_tile != 132 || P.tprobs_host.empty())
+        return fail("m2f_plan_fused_adam_setup: needs a bf16 train plan whose weight-gradient table runs in the eight-phase form (M2F_TABLE_TILE=132)");
+    if (!P.ext_wshadow || P.ext_wshadow != param_shadow) return fail("m2f_plan_fused_adam_setup: the plan must share the model's parameter-shadow buffer (m2f_plan_create_shared)");
+    if (!params || !exp_avg || !exp_avg_sq || !hyper_dev) return fail("m2f_plan_fused_adam_setup: NULL buffer");
+    if (params != P.params) return fail("m2f_plan_fused_adam_setup: `params` is not the plan's parameter buffer");
+    AdamTable at;
+    if (adam_table(P.cfg, at)) return 1;
+    // every table problem writes a block of whole rows of ONE 2-D parameter's gradient: find the tensor, its shadows, the first row
+    std::vector<GemmProblem> tp = P.tprobs_host;
+    std::vector<long long> covered(P.pm.mats.size(), 0);
+    for (GemmProblem& q : tp) {
+        const long long e = q.c - P.grads;
+        size_t mi = P.pm.mats.size();
+        for (size_t i = 0; i < P.pm.mats.size(); ++i) {
+            const ParamMap::Mat& m = P.pm.mats[i];
+            if (e >= (long long)m.off && e < (long long)m.off + (long long)m.rows * m.cols) { mi = i; break; }
+        }
+        if (mi == P.pm.mats.size()) return fail("m2f_plan_fused_adam_setup: a weight-gradient problem does not write a 2-D parameter's gradient");
+        const ParamMap::Mat& m = P.pm.mats[mi];
+        const long long rel = e - (long long)m.off;
+        // (a block of rows r0.. x columns c0.. of the parameter: whole matrices, the q / k / v row blocks of a fusion layer's in-projection,
+        //  the column halves of a Linear over a never-materialised torch.cat)
+        const int r0 = (int)(rel / m.cols), c0 = (int)(rel % m.cols), ldd = (m.cols + 7) & ~7, ldt = (m.rows + 7) & ~7;
+        if (q.ldc != m.cols || c0 + q.N > m.cols || r0 + q.M > m.rows || q.res || q.gate)
+            return fail("m2f_plan_fused_adam_setup: a weight-gradient problem is not a block of its parameter");
+        q.res = reinterpret_cast<const float*>(param_shadow + m.soff + (size_t)r0 * ldd + c0);
+        q.gate = reinterpret_cast<const float*>(param_shadow + m.soff_t + (size_t)c0 * ldt + r0);
+        q.ldres = ldd; q.ldgate = ldt;
+        covered[mi] += (long long)q.M * q.N;
+    }
+    // what is left for the shadow-writing Adam kernel: every item of the optimizer's tensor table except the fully covered matrices
+    std::vector<AdamItem> items;
+    std::vector<int> tb;
+    int tiles = 0;
+    for (const AdamItem& it0 : at.items) {
+        bool fused = false;
+        if (it0.rows > 0)
+            for (size_t i = 0; i < P.pm.mats.size(); ++i)
+                if ((long long)P.pm.mats[i].off == it0.off) {
+                    const long long all = (long long)P.pm.mats[i].rows * P.pm.mats[i].cols;
+                    if (covered[i] == all) fused = true;
+                    else if (covered[i] != 0) return fail("m2f_plan_fused_adam_setup: a parameter is only partly covered by the weight-gradient table");
+                }
+        if (fused) continue;
+        AdamItem it = it0;
+        it.tile_begin = tiles;
+        tb.push_back(tiles);
+        tiles += it.rows > 0 ? ((it.rows + 63) / 64) * it.tiles_c : (it.cols + 4095) / 4096;
+        items.push_back(it);
+    }
+    tb.push_back(tiles);
+    if (items.empty() || items.size() > M2F_ADAM_MAX_ITEMS) return fail("m2f_plan_fused_adam_setup: no / too many residual tensors");
+    const size_t o_tab = 256, o_items = o_tab + ((tp.size() * sizeof(GemmProblem) + 255) & ~(size_t)255),
+                 o_tb = o_items + ((items.size() * sizeof(AdamItem) + 255) & ~(size_t)255), bytes = o_tb + tb.size() * sizeof(int) + 256;
+    if (P.fused_dev) { (void)hipFree(P.fused_dev); P.fused_dev = nullptr; }
+    M2F_HIP(hipMalloc(&P.fused_dev, bytes));
+    char* d = static_cast<char*>(P.fused_dev);
+    M2FAdamFuse af;
+    af.p = params; af.g_base = P.grads; af.m = exp_avg; af.v = exp_avg_sq; af.hyper = hyper_dev; af.gs_ptr = grad_scale_ptr;
+    M2F_HIP(hipMemcpy(d, &af, sizeof(af), hipMemcpyHostToDevice));
+    M2F_HIP(hipMemcpy(d + o_tab, tp.data(), tp.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
+    M2F_HIP(hipMemcpy(d + o_items, items.data(), items.size() * sizeof(AdamItem), hipMemcpyHostToDevice));
+    M2F_HIP(hipMemcpy(d + o_tb, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+    P.wg_tab_adam = P.wg_tab;
+    P.wg_tab_adam.table = reinterpret_cast<const GemmProblem*>(d + o_tab);
+    P.wg_tab_adam.adam = reinterpret_cast<const M2FAdamFuse*>(d);
+    P.fz_p = params; P.fz_m = exp_avg; P.fz_v = exp_avg_sq; P.fz_sh = param_shadow; P.fz_hyper = hyper_dev; P.fz_gs = grad_scale_ptr;
+    P.fz_items = reinterpret_cast<const AdamItem*>(d + o_items); P.fz_tb = reinterpret_cast<const int*>(d + o_tb);
+    P.fz_n_items = (int)items.size(); P.fz_tiles = tiles;
+    P.fused_ready = true;
+    return 0;
+}
+
+int m2f_plan_fused_adam(m2f_plan* plan, int on) {
+    if (!plan) return fail("m2f_plan_fused_adam: NULL plan (destroyed?)");
+    if (on && !plan->fused_ready) return fail("m2f_plan_fused_adam: call m2f_plan_fused_adam_setup first");
+    plan->fused_on = on != 0;
+    return 0;
+}
+
+int m2f_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, m2f_stream_t stream) {
+    if (!hyper_dev || step < 1) return fail("m2f_adam_hyper: NULL buffer / step < 1");
+    M2F_HIP(m2f_launch_adam_hyper(hyper_dev, lr, beta1, beta2, eps, weight_decay, step, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int m2f_plan_skipped_copies(m2f_plan* plan) { return plan ? plan->n_no_f32 : -1; }
 
 int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
@@ -1710,7 +1823,8 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!P.train) return fail("m2f_step needs a train plan");
     if (!use_graph || !P.warmed) { P.warmed = true; return step_body(P, label_smoothing, use_class_weights, normalise, s); }
-    if (P.gexec && (P.g_ls != label_smoothing || P.g_cw != use_class_weights || P.g_norm != normalise || P.g_fresh != (int)P.params_fresh)) {
+    if (P.gexec && (P.g_ls != label_smoothing || P.g_cw != use_class_weights || P.g_norm != normalise || P.g_fresh != (int)P.params_fresh ||
+                    P.g_fused != (int)P.fused_on)) {
         (void)hipGraphExecDestroy(P.gexec);
         P.gexec = nullptr;
     }
@@ -1724,7 +1838,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
         e = hipGraphInstantiate(&P.gexec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { P.gexec = nullptr; return hipfail(e, "hipGraphInstantiate"); }
-        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise; P.g_fresh = (int)P.params_fresh;
+        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise; P.g_fresh = (int)P.params_fresh; P.g_fused = (int)P.fused_on;
     }
     M2F_HIP(hipGraphLaunch(P.gexec, s));
     return 0;

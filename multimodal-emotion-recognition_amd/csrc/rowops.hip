@@ -464,12 +464,12 @@ __device__ __forceinline__ float adam_grad1(const void* g, long long o) {
 // see ops.h (AdamItem).  Persistent 1-D grid over tiles [tile_first, total_tiles) of items[0, n_items) (tile_begin[] holds absolute
 // tile numbers); tile -> item by bisection of the prefix array (kept in LDS).
 template <bool G16>
-__global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
-                                                              float* __restrict__ v, uint16_t* __restrict__ sh,
-                                                              const AdamItem* __restrict__ items, const int* __restrict__ tile_begin,
-                                                              int n_items, int tile_first, int total_tiles, float lr_bc1, float beta1,
-                                                              float beta2, float eps, float wd, float inv_sqrt_bc2,
-                                                              const float* __restrict__ gs_ptr) {
+__device__ __forceinline__ void adam_shadow_body(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, uint16_t* __restrict__ sh,
+                                                 const AdamItem* __restrict__ items, const int* __restrict__ tile_begin,
+                                                 int n_items, int tile_first, int total_tiles, float lr_bc1, float beta1,
+                                                 float beta2, float eps, float wd, float inv_sqrt_bc2,
+                                                 const float* __restrict__ gs_ptr) {
     __shared__ float tile[64][65];
     __shared__ int tb[M2F_ADAM_MAX_ITEMS + 1];
     const int tid = threadIdx.x;
@@ -570,6 +570,24 @@ __global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict_
         }
         __syncthreads();
     }
+}
+
+template <bool G16>
+__global__ __launch_bounds__(256) void m2f_adam_shadow_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, uint16_t* __restrict__ sh,
+                                                              const AdamItem* __restrict__ items, const int* __restrict__ tile_begin,
+                                                              int n_items, int tile_first, int total_tiles, float lr_bc1, float beta1,
+                                                              float beta2, float eps, float wd, float inv_sqrt_bc2,
+                                                              const float* __restrict__ gs_ptr) {
+    adam_shadow_body<G16>(p, g, m, v, sh, items, tile_begin, n_items, tile_first, total_tiles, lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2, gs_ptr);
+}
+// the same update with the step-dependent factors read from device memory (m2f_launch_adam_hyper): a node of the captured step graph
+__global__ __launch_bounds__(256) void m2f_adam_shadow_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                                  float* __restrict__ v, uint16_t* __restrict__ sh,
+                                                                  const AdamItem* __restrict__ items, const int* __restrict__ tile_begin,
+                                                                  int n_items, int total_tiles, const float* __restrict__ hy,
+                                                                  const float* __restrict__ gs_ptr) {
+    adam_shadow_body<false>(p, g, m, v, sh, items, tile_begin, n_items, 0, total_tiles, hy[0], hy[1], hy[2], hy[3], hy[4], hy[5], gs_ptr);
 }
 
 template <bool BWD>
@@ -918,6 +936,26 @@ hipError_t m2f_launch_adam_shadowed(float* p, const void* g, int g_is_bf16, floa
     else
         hipLaunchKernelGGL(m2f_adam_shadow_kernel<false>, dim3(blocks), dim3(256), 0, stream, p, g, m, v, shadow, items, tile_begin, n_items,
                            tile_first, total_tiles, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale_ptr);
+    return hipGetLastError();
+}
+
+// step-dependent factors of the update in device memory (a captured graph cannot take them as kernel arguments): one thread
+__global__ void m2f_adam_hyper_kernel(float* __restrict__ h, float lr_bc1, float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2) {
+    h[0] = lr_bc1; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = wd; h[5] = inv_sqrt_bc2; h[6] = 0.f; h[7] = 0.f;
+}
+hipError_t m2f_launch_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream) {
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);       // as m2f_launch_adam_shadowed computes them
+    hipLaunchKernelGGL(m2f_adam_hyper_kernel, dim3(1), dim3(1), 0, stream, hyper_dev, (float)(lr / bc1), beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / sqrt(bc2)));
+    return hipGetLastError();
+}
+// the shadow-writing kernel with those factors read from `hyper_dev` (m2f_adam_shadow_dev_kernel: same body, same arithmetic)
+hipError_t m2f_launch_adam_shadowed_dev(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items, const int* tile_begin,
+                                        int n_items, int total_tiles, const float* hyper_dev, const float* grad_scale_ptr, hipStream_t stream) {
+    if (n_items < 1 || n_items > M2F_ADAM_MAX_ITEMS || total_tiles < 1 || !items || !tile_begin || !shadow || !hyper_dev) return hipErrorInvalidValue;
+    const int blocks = total_tiles < 256 * 8 ? total_tiles : 256 * 8;
+    hipLaunchKernelGGL(m2f_adam_shadow_dev_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, shadow, items, tile_begin, n_items, total_tiles,
+                       hyper_dev, grad_scale_ptr);
     return hipGetLastError();
 }
 

@@ -395,9 +395,12 @@ class M2FNet(nn.Module):
     # -- fused fast path (forward + criterion + backward as one launch list / hipGraph) ---------------
     def train_step(self, text, audio, mask, emotion, label_smoothing: float = 0.1,
                    class_weights: Optional[torch.Tensor] = None, normalise: bool = True,
-                   use_graph: bool = True) -> torch.Tensor:
+                   use_graph: bool = True, optimizer=None) -> torch.Tensor:
         """Body of reference src/train.py:227-230 in one call: returns the (device) loss scalar and leaves
-        the gradients in ``p.grad`` (views of the flat buffer)."""
+        the gradients in ``p.grad`` (views of the flat buffer).
+        optimizer (a ``FusedAdam`` of this model): the call is ALSO ``optimizer.step()`` (src/train.py:231) - in bf16 mode the
+        weight-gradient launch applies the update itself (``FusedAdam.prepare_fused``; the matrices' ``.grad`` is then not written),
+        otherwise the optimizer's own kernel runs behind the step."""
         eng = self.engine(mask.device)
         B, L = mask.shape
         valid = int((~mask.bool()).sum()) if self.packed else None
@@ -407,7 +410,17 @@ class M2FNet(nn.Module):
             plan.set_inputs(text if self.text_enabled else None, audio if self.audio_enabled else None, mask, emotion)
             if class_weights is not None:
                 plan.class_w[: class_weights.numel()].copy_(class_weights)
-            return plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+            if optimizer is None:
+                return plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+            plan.params_fresh(eng.shadows_fresh())
+            if optimizer.prepare_fused(plan):
+                out = plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+                optimizer.finish_fused(plan)
+                return out
+            out = plan.step(label_smoothing, class_weights is not None, normalise, use_graph)
+            eng.publish_grads()
+            optimizer.step()
+            return out
 
         if use_graph:                                    # capture / replay on the engine's own stream
             cur = torch.cuda.current_stream(eng.device)

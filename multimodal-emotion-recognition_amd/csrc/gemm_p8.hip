@@ -6,9 +6,12 @@
 #include <algorithm>
 #include <string>
 
-// M2F_P8_SKEW (read once): cycles per k-tile the start skew assumes (default 3000; 0 = no skew; + 2^30: skew workgroups without slack too)
+// M2F_P8_SKEW (read once): cycles per k-tile the start skew assumes (0 = no skew); + 2^29: whole XCDs are skewed against each other (default:
+// the workgroups of an XCD stay in step and share operand panels in their L2 - 502 MB of fabric reads per C3 table launch against 669 MB
+// with the skew inside an XCD and 553 MB without any, at the same 245-247 us, profiles/r04_dev_start_skew_ab.txt); + 2^30: skew
+// workgroups without slack too
 static int p8_skew_env() {
-    static const int v = getenv("M2F_P8_SKEW") ? atoi(getenv("M2F_P8_SKEW")) : 3000;
+    static const int v = getenv("M2F_P8_SKEW") ? atoi(getenv("M2F_P8_SKEW")) : (0x20000000 | 3000);
     return v;
 }
 

@@ -1775,6 +1775,23 @@ int m2f_plan_status(m2f_plan* plan, uint32_t* out8) {
     return 0;            // (no kernel of the launch lists can give up: nothing waits on another workgroup)
 }
 
+/* diagnostic (tools/chain_floor.py): the grouped GEMM launches of the forward list and of the backward chain, in order, as
+ * [phase (0 fwd, 2 bwd), layout, part of the model, problems, then M, N, K0 + K1 per problem] records; returns the ints written (< 0: too small) */
+int m2f_plan_gemm_shapes(m2f_plan* plan, int* out, int max_ints) {
+    if (!plan || !out) return -1;
+    int n = 0;
+    for (int phase = 0; phase < 2; ++phase)
+        for (const Launch& l : phase == 0 ? plan->fwd : plan->bwd) {
+            if (l.kind != OP_GEMM) continue;
+            if (n + 4 + 3 * l.gb.count > max_ints) return -2;
+            out[n++] = phase == 0 ? 0 : 2; out[n++] = l.layout; out[n++] = l.group; out[n++] = l.gb.count;
+            for (int i = 0; i < l.gb.count; ++i) {
+                out[n++] = l.gb.pr[i].M; out[n++] = l.gb.pr[i].N; out[n++] = l.gb.pr[i].a.k[0] + l.gb.pr[i].a.k[1];
+            }
+        }
+    return n;
+}
+
 int m2f_plan_num_launches(m2f_plan* plan, int phase) {
     if (!plan) return -1;
     if (phase == 0) return (int)(plan->fwd.size() + (plan->params_fresh ? 0 : plan->param_casts.size()) + plan->input_casts.size());

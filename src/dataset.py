@@ -29,10 +29,24 @@ def build_dialogue_index(dialogue_ids, utterance_ids):
     return list(order.keys()), index
 
 
+def tokenised_contexts(table, tokenizer, max_tokens=64):
+    """Token ids of every utterance WITH ITS CONTEXT, the input of the in-loop text encoder (BASELINE C5; `runtime.text_encoder`):
+    the strings of the reference's text feature extractor (src/feature_extractors/text/dataset.py:28-34 -> utils.py:61-92,
+    restated in mer_amd.text_context), tokenised by the CALLER's tokenizer the way that dataset does (:36-44: padding to
+    max_length, truncation) -> (int64 ids [N, max_tokens], int64 mask [N, max_tokens]) in table row order."""
+    from mer_amd.text_context import build_contexts
+    texts = build_contexts(table["Utterance"].tolist(), table["Dialogue_ID"].tolist(), table["Utterance_ID"].tolist(), tokenizer.sep_token)
+    enc = tokenizer(texts, padding="max_length", truncation=True, max_length=int(max_tokens), return_tensors="pt")
+    return enc["input_ids"].to(torch.int64), enc["attention_mask"].to(torch.int64)
+
+
 class Dataset(torch.utils.data.Dataset):
-    def __init__(self, mode="train", text_embeddings=None, audio_embeddings=None, table=None):
+    def __init__(self, mode="train", text_embeddings=None, audio_embeddings=None, table=None, token_ids=None, token_mask=None):
+        """token_ids / token_mask ([N, S] int64, rows = table rows; `tokenised_contexts`): items and batches ALSO carry "text_ids" /
+        "text_mask" - what the in-loop text encoder consumes instead of the pre-extracted "text" rows (`runtime.text_encoder`)."""
         super().__init__()
         self.mode = mode
+        self.token_ids, self.token_mask = token_ids, token_mask
         if text_embeddings is None or audio_embeddings is None:
             config = get_config()
             with open(os.path.join(os.path.abspath(config.embeddings.text), f"{mode}.pkl"), "rb") as f:
@@ -52,8 +66,12 @@ class Dataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         rows = torch.as_tensor(self.rows[idx])
-        return {"text": self.text_embeddings[rows], "audio": self.audio_embeddings[rows],
+        item = {"text": self.text_embeddings[rows], "audio": self.audio_embeddings[rows],
                 "emotion": [e.reshape(1) for e in self._labels[rows]]}
+        if self.token_ids is not None:
+            item["text_ids"] = self.token_ids[rows]
+            item["text_mask"] = self.token_mask[rows] if self.token_mask is not None else torch.ones_like(item["text_ids"])
+        return item
 
     def get_labels(self):
         return self.text["Emotion"].to_numpy()
@@ -69,7 +87,16 @@ def collate_fn(batch):
         n = d["text"].shape[0]
         text[i, :n], audio[i, :n] = d["text"], d["audio"]
         emotion[i, :n] = torch.cat([torch.as_tensor(e).reshape(1) for e in d["emotion"]]).to(torch.int64)
-    return {"text": text, "audio": audio, "padding_mask": emotion == -1, "emotion": emotion}
+    out = {"text": text, "audio": audio, "padding_mask": emotion == -1, "emotion": emotion}
+    if "text_ids" in batch[0]:                                     # in-loop text encoder: [B, L, S] token ids + attention mask, zero on pads
+        S = batch[0]["text_ids"].shape[1]
+        ids = torch.zeros(B, L, S, dtype=torch.int64)
+        msk = torch.zeros(B, L, S, dtype=torch.int64)
+        for i, d in enumerate(batch):
+            n = d["text_ids"].shape[0]
+            ids[i, :n], msk[i, :n] = d["text_ids"], d["text_mask"]
+        out["text_ids"], out["text_mask"] = ids, msk
+    return out
 
 
 class DeviceLoader:

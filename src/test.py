@@ -38,7 +38,7 @@ def test(model, dl_test, device):
     model.eval()
     with torch.inference_mode():
         for batch in tqdm(dl_test, total=len(dl_test)):
-            text, audio, emotion, padding_mask = move_batch(batch, device)
+            text, audio, emotion, padding_mask = move_batch(batch, device, text_encoder=getattr(model, "text_encoder", None))
             scores.update(model(text, audio, padding_mask), emotion)
     return scores.result()
 

@@ -63,6 +63,28 @@ def build_scheduler(solver, optimizer):
     return torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=solver.scheduler.gamma)
 
 
+TEXT_ENCODER_GEOMETRY = {"base": dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072),
+                         "large": dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)}
+
+
+def build_text_encoder(te_cfg, d_text, device):
+    """`runtime.text_encoder`: {enabled, precision: fp32 | bf16 | fp8, geometry: base | large | a dict of RobertaConfig fields,
+    checkpoint: path of a state_dict in transformers.RobertaModel(add_pooling_layer=False) key layout (the encoder of the reference's
+    TextERC, src/feature_extractors/text/model.py:16) or null = random weights}."""
+    from mer_amd.roberta import RobertaEncoder
+    geo = te_cfg.get("geometry", "base")
+    cfg = dict(TEXT_ENCODER_GEOMETRY[geo]) if isinstance(geo, str) else dict(geo)
+    for k, v in dict(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5, hidden_act="gelu").items():
+        cfg.setdefault(k, v)
+    if cfg["hidden_size"] != d_text:
+        raise ValueError(f"runtime.text_encoder produces {cfg['hidden_size']}-wide rows but model.TEXT.embedding_size is {d_text}")
+    enc = RobertaEncoder(cfg, precision=te_cfg.get("precision", "bf16"))
+    ck = te_cfg.get("checkpoint", None)
+    if ck:
+        enc.load_state_dict(torch.load(os.path.abspath(ck), map_location="cpu"))
+    return enc.to(device).eval()
+
+
 def start_wandb(config):
     if wandb is None:
         raise RuntimeError("wandb.enabled is set but the wandb package is not installed")
@@ -104,7 +126,22 @@ def main(config=None):
         print(f"Using device {device}..." + (f" ({world} ranks)" if world > 1 else ""))
     torch.manual_seed(int(_runtime(config, "seed", 0)))       # identical replicas and identical shuffles on every rank
 
-    train_set, val_set = Dataset(mode="train"), Dataset(mode="val")
+    te_on = bool((_runtime(config, "text_encoder", None) or {}).get("enabled", False))
+    if te_on:
+        # the tokenizer is the caller's: a LOCAL directory with the files of the reference's RobertaTokenizer (text/dataset.py:9,42 fetch
+        # 'roberta-base' by name - there is no network here)
+        tok_dir = _runtime(config, "text_encoder").get("tokenizer", None)
+        if not tok_dir:
+            raise RuntimeError("runtime.text_encoder.enabled needs runtime.text_encoder.tokenizer: a local directory with the tokenizer files")
+        from transformers import AutoTokenizer
+        from dataset import tokenised_contexts
+        tok = AutoTokenizer.from_pretrained(os.path.abspath(tok_dir))
+        max_tokens = int(_runtime(config, "text_encoder").get("max_tokens", 64))
+        train_set, val_set = Dataset(mode="train"), Dataset(mode="val")
+        for ds_ in (train_set, val_set):
+            ds_.token_ids, ds_.token_mask = tokenised_contexts(ds_.text, tok, max_tokens)
+    else:
+        train_set, val_set = Dataset(mode="train"), Dataset(mode="val")
     if _runtime(config, "device_batcher", False):          # embedding tables in HBM, one gather kernel per batch
         dl_train = DeviceLoader(train_set, device=device, seed=_runtime(config, "seed", 0), **config.train.data_loader)
         dl_val = DeviceLoader(val_set, device=device, **config.val.data_loader)
@@ -119,6 +156,12 @@ def main(config=None):
     # how train() runs the loop body: (fused m2f_step instead of forward / criterion / backward, as one hipGraph)
     model.step_mode = (bool(_runtime(config, "fused_step", True)), bool(_runtime(config, "use_graph", True)))
     model.fused_optimizer = bool(_runtime(config, "fused_optimizer", False))
+    te_cfg = _runtime(config, "text_encoder", None)
+    if te_cfg and te_cfg.get("enabled", False):
+        # BASELINE config C5: the text rows are computed in the loop from token ids (Dataset(token_ids=...)) instead of read from
+        # embeddings/<text>/<mode>.pkl.  Built OUTSIDE the fusion model (object.__setattr__: not a sub-module - its weights are
+        # neither in M2FNet's state_dict / checkpoint format nor in the optimizer, as in the reference, which trains it in its own stage).
+        object.__setattr__(model, "text_encoder", build_text_encoder(te_cfg, config.model.TEXT.embedding_size, device))
     criterion = build_criterion(config.solver, train_set, device)
     optimizer = FusedAdam(model, lr=config.solver.lr, weight_decay=config.solver.weight_decay)
     if world > 1:
@@ -229,7 +272,7 @@ def train(model, dl_train, criterion, optimizer, epoch, wandb_log, device):
     running = 0.0
     progress = tqdm(enumerate(dl_train), total=len(dl_train), desc=f"Epoch {epoch}", disable=_rank() != 0)
     for step, batch in progress:
-        text, audio, emotion, padding_mask = move_batch(batch, device, non_blocking=True)
+        text, audio, emotion, padding_mask = move_batch(batch, device, non_blocking=True, text_encoder=getattr(model, "text_encoder", None))
         if dp_step is not None:
             # sharded step: local sum-gradient -> RCCL all-reduce with the global denominator -> fused Adam, all inside
             loss = dp_step(text, audio, padding_mask, emotion, label_smoothing=criterion.label_smoothing,
@@ -284,7 +327,7 @@ def validate(model, dl_val, criterion, device):
     scores, loss_total = BatchScores(), 0.0
     with torch.inference_mode():
         for batch in tqdm(_rank_share(dl_val, rank, world), total=(len(dl_val) - rank + world - 1) // world, desc="Validation", disable=rank != 0):
-            text, audio, emotion, padding_mask = move_batch(batch, device)
+            text, audio, emotion, padding_mask = move_batch(batch, device, text_encoder=getattr(model, "text_encoder", None))
             logits = model(text, audio, padding_mask)
             loss_total += criterion(logits.permute(0, 2, 1), emotion).item()
             scores.update(logits, emotion)

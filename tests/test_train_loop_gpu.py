@@ -237,3 +237,70 @@ def test_busy_plan_survives_eviction_and_closed_plan_raises():
     with pytest.raises(runtime.HipError, match="closed"):
         pa.forward()
     torch.cuda.synchronize()
+
+
+def test_training_loop_with_in_loop_text_encoder(tmp_path, monkeypatch):
+    """BASELINE config C5 through the drop-in (runtime.text_encoder): batches carry token ids, `move_batch` turns them into the text rows
+    with the RoBERTa-shaped encoder's [CLS] states (mer_amd.roberta on the HIP kernels, inference mode), `training_loop` trains the
+    fusion model on them - forward, criterion, backward, optimizer, validation, checkpoint, all unchanged."""
+    monkeypatch.chdir(ROOT)
+    import dataset as ds
+    import train as tr
+    from metrics import move_batch
+    from utils import AttrDict, get_config
+    cfg = AttrDict(dict(get_config()))
+    model_cfg = synth._cfg(40, 64, 64, 4, 4, 4, 1, 1, 1, dropout=0.0)
+    cfg.model = AttrDict(model_cfg)
+    cfg.solver = AttrDict(dict(cfg.solver, epochs=3, lr=2e-3, early_stopping=AttrDict(enabled=False, patience=2, restore_best_weights=True),
+                               scheduler=AttrDict(enabled=False, scheduler_fn="ExponentialLR", gamma=0.9)))
+    cfg.checkpoint = AttrDict(save_path=str(tmp_path / "ck" / "m2fnet.pth"), load_path=str(tmp_path / "ck" / "m2fnet.pth"),
+                              save_checkpoint=True, load_checkpoint=False)
+    te_cfg = {"enabled": True, "precision": "bf16",
+              "geometry": dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=60, max_position_embeddings=40)}
+    S = 12
+
+    def tokens(d, seed):                                           # the label is written into the tokens: the encoder's rows carry it
+        g = torch.Generator().manual_seed(seed)
+        n = len(d._labels)
+        ids = torch.randint(10, 60, (n, S), generator=g)
+        ids[:, 0] = 0
+        ids[:, 1] = 3 + d._labels
+        ids[:, 2] = 3 + d._labels
+        lens = torch.randint(4, S + 1, (n,), generator=g)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+        ids[mask == 0] = 1
+        return ids, mask
+    d_train, d_val = _dataset(40, 64, 40, 1), _dataset(12, 64, 40, 2)
+    for d, seed in ((d_train, 5), (d_val, 6)):
+        d.token_ids, d.token_mask = tokens(d, seed)
+        d.text_embeddings = torch.zeros_like(d.text_embeddings)     # the pre-extracted rows must not be what the model learns from
+    dl_train = torch.utils.data.DataLoader(d_train, collate_fn=ds.collate_fn, batch_size=8, shuffle=True)
+    dl_val = torch.utils.data.DataLoader(d_val, collate_fn=ds.collate_fn, batch_size=8, shuffle=False)
+    device = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = tr.M2FNet(cfg.model).to(device)
+    enc = tr.build_text_encoder(te_cfg, 64, device)
+    object.__setattr__(model, "text_encoder", enc)
+    assert "text_encoder" not in dict(model.named_modules()) and all("text_encoder" not in k for k in model.state_dict())
+    # what move_batch hands to the model: [CLS] rows at valid slots, zeros at pads
+    batch = next(iter(dl_val))
+    assert batch["text_ids"].shape[:2] == batch["padding_mask"].shape and batch["text_ids"].shape[2] == S
+    text, audio, emotion, mask = move_batch(batch, device, text_encoder=enc)
+    valid = ~batch["padding_mask"]
+    ref = enc.cls_embeddings(batch["text_ids"][valid].to(device), batch["text_mask"][valid].to(device)).float()
+    assert torch.equal(text[valid.to(device)], ref) and float(text[~valid.to(device)].abs().max() if (~valid).any() else 0.0) == 0.0
+    assert text.shape[2] == 64 and torch.isfinite(text).all()
+    crit = tr.M2FCrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)
+    opt = tr.FusedAdam(model, lr=cfg.solver.lr, weight_decay=cfg.solver.weight_decay)
+    out = tr.training_loop(model, dl_train, dl_val, crit, opt, None, 0, cfg, device)
+    losses = out["loss_values"]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
+    assert np.isfinite(out["val_loss_values"]).all()
+    # the same rows, pre-extracted the reference's way (text/embeddings.py:64-90 = text_context.cls_dump), train the same model the same way
+    # on its first batch: the in-loop path is the two-stage path without the files
+    from mer_amd.text_context import cls_dump
+    items = [{"idx": torch.arange(len(d_val._labels)), "text": d_val.token_ids.to(device), "attention_mask": d_val.token_mask.to(device)}]
+    dumped = cls_dump(enc, items, len(d_val._labels), str(tmp_path / "emb"), "val")
+    rows = torch.as_tensor(d_val.rows[0])
+    got = move_batch(ds.collate_fn([d_val[0]]), device, text_encoder=enc)[0][0, : len(rows)].cpu()
+    assert (got - dumped[rows]).abs().max().item() < 2e-2          # (bf16 mode: batch composition changes nothing but the tile edges)

@@ -192,6 +192,14 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
             plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
             stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
 
+        if world > 1 and not split and stepper.reducer.exchange == "bf16" and stepper.grad_bf16:
+            # bf16 exchange: the step leaves its gradients rounded in the exchange buffer itself (the weight-gradient launch writes bf16 dW:
+            # no fp32 dW round trip and no rounding pass before the all-reduce)
+            try:
+                plan.grad_bf16(stepper.reducer.buf16)
+                stepper.reducer.buf16_filled = True
+            except runtime.HipError:
+                stepper.reducer.buf16_filled = False
         eng.publish_grads()
         for _ in range(max(warmup, 3)):                # >= 3: eager warm-up, graph capture, first replay
             one_step()
@@ -251,7 +259,8 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
             red.stub = False
             one_step()                                         # (leave the replicas in step with each other again: real sums)
             comm = {"algorithm": red.algorithm, "exchange_dtype": red.exchange, "buckets": len(red.param_chunks if red.exchange == "bf16" else red.chunks),
-                    "overlap_with_backward": bool(split), "bytes_per_step": red.bytes_per_step(),
+                    "overlap_with_backward": bool(split), "gradients_rounded_by": "the step (bf16 dW from the weight-gradient launch)" if red.buf16_filled else ("a pass over the fp32 buffer" if red.exchange == "bf16" else None),
+                    "bytes_per_step": red.bytes_per_step(),
                     "allreduce_alone_ms": alone_ms, "algbw_GBps_alone": red.bytes_per_step() / (alone_ms * 1e-3) / 1e9,
                     "step_without_collectives_ms": nocomm_ms, "exposed_ms": elapsed / steps * 1e3 - nocomm_ms, "steps_each": n_c,
                     "note": "exposed_ms = ms_per_step - the same step with the collectives stubbed to no-ops on identical data; "

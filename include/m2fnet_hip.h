@@ -267,6 +267,13 @@ int m2f_plan_fused_adam_setup(m2f_plan* plan, float* params, float* exp_avg, flo
 int m2f_plan_fused_adam(m2f_plan* plan, int on);
 int m2f_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, m2f_stream_t stream);
 
+/* Gradients left as bf16 (round 4; the data-parallel bf16 exchange, multimodal-emotion-recognition_amd/dp.py): after m2f_plan_grad_bf16(plan, g16)
+ * a step writes EVERY gradient, rounded once to bf16, at its element index of g16 (n_params uint16, 16-byte aligned) - the weight
+ * gradients of the table launch directly (no fp32 dW: -2 bytes per parameter written, and no rounding pass over the fp32 buffer before
+ * the all-reduce), all others through one cast launch behind the backward.  The fp32 buffer then holds only those others (and the loss
+ * tail).  m2f_plan_grad_bf16(plan, NULL) restores fp32 gradients.  Same bits as rounding the fp32 gradients of a plain step. */
+int m2f_plan_grad_bf16(m2f_plan* plan, uint16_t* grads_bf16);
+
 /* The 256x256-tile bf16 GEMM on the eight-phase schedule (csrc/gemm_p8.h; round 4), bf16 operands handed over directly - the kernel
  * the weight-gradient table launch (rc = 1) and the text encoder's launches (rc = 0) run, for kernel-level tests and measurements.
  *   rc = 0: C[M,N] = act(A[M,K] B[N,K]^T + bias) + res   (nn.Linear forward: src/feature_extractors/text/model.py:16-21's encoder

@@ -344,6 +344,9 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
         const int ldres = P.ldres;
         uint16_t* __restrict__ C16 = EPI == 2 && !(P.flags & GF_NO_BF16) ? reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c)) : nullptr;
         const bool relu_out = P.flags & GF_RELU_OUT, gelu = P.flags & GF_GELU_OUT, no32 = EPI == 2 && (P.flags & GF_NO_F32) && C16;
+        // EPI 1, `res` set: the weight gradient leaves as bf16 INSTEAD of fp32, at the same element index of a bf16 gradient buffer (the
+        // data-parallel bf16 exchange sends that buffer as it is: no fp32 dW round trip, no rounding pass; m2f_plan_grad_bf16)
+        uint16_t* __restrict__ G16 = EPI == 1 ? reinterpret_cast<uint16_t*>(const_cast<float*>(P.res)) : nullptr;
 
         auto quad = [&](auto a_tag, auto b_tag, const bf16x8 (&bb)[2][2]) {
             constexpr int AH = decltype(a_tag)::value, BH = decltype(b_tag)::value;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
             __builtin_amdgcn_s_barrier();
             continue;                                      // (next output tile)
         }
-        const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) &&
+        const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) && (!G16 || (reinterpret_cast<uintptr_t>(G16) & 7) == 0) &&
                          (!res || (((ldres & 3) == 0) && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!C16 || (reinterpret_cast<uintptr_t>(C16) & 7) == 0);
         const bool whole = vec && m0 + C::BM <= Mm && n0 + C::BN <= Nn;               // block-uniform
@@ -660,7 +663,12 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                             f32x4 v = acc[a][b][i][j];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = element(v[e], bv[e], rv[i][e]);
-                            if (!no32) *reinterpret_cast<f32x4*>(Cp + oc) = v;
+                            if (EPI == 1 && G16) {
+                                uint2 hh;
+                                hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
+                                hh.y = (uint32_t)m2f_bf16_bits(v[2]) | ((uint32_t)m2f_bf16_bits(v[3]) << 16);
+                                *reinterpret_cast<uint2*>(G16 + oc) = hh;
+                            } else if (!no32) *reinterpret_cast<f32x4*>(Cp + oc) = v;
                             if constexpr (EPI == 2) {
                                 if (C16) {
                                     uint2 hh;
@@ -693,7 +701,8 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                                     if (res && in) rvv = res[(size_t)((uint32_t)(row * ldres + col + e))];
                                 }
                                 const float x = element(v[e], bvv, rvv);
-                                if (in) {
+                                if (in && EPI == 1 && G16) G16[oc] = m2f_bf16_bits(x);
+                                else if (in) {
                                     Cp[oc] = x;                         // (edge tiles keep the fp32 store whatever GF_NO_F32 says, as the ring form does)
                                     if constexpr (EPI == 2) { if (C16) C16[oc] = m2f_bf16_bits(x); }
                                 }

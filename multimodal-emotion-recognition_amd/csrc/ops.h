@@ -326,6 +326,7 @@ hipError_t m2f_launch_adam_shadowed(float* p, const void* g, int g_is_bf16, floa
                                     float beta2, float eps, float weight_decay, int step, const float* grad_scale_ptr,
                                     hipStream_t stream);
 
+hipError_t m2f_launch_cast_items(const float* src, uint16_t* dst, const AdamItem* items, const int* tile_begin, int n_items, int total_tiles, hipStream_t stream);
 hipError_t m2f_launch_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
 hipError_t m2f_launch_adam_shadowed_dev(float* p, const float* g, float* m, float* v, uint16_t* shadow, const AdamItem* items, const int* tile_begin,
                                         int n_items, int total_tiles, const float* hyper_dev, const float* grad_scale_ptr, hipStream_t stream);

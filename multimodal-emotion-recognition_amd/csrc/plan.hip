@@ -279,6 +279,14 @@ struct m2f_plan {
     const float* fz_hyper = nullptr; const float* fz_gs = nullptr;
     const AdamItem* fz_items = nullptr; const int* fz_tb = nullptr; int fz_n_items = 0, fz_tiles = 0;
     int g_fused = -1;
+    // gradients left as bf16 (m2f_plan_grad_bf16): the table launch writes dW as bf16 into `g16` (same element index as the fp32 buffer),
+    // one cast launch at the end of the backward rounds every other gradient into it
+    GemmBatch wg_tab_g16;
+    bool g16_ready = false, g16_on = false;
+    void* g16_dev = nullptr;                     // GemmProblem[] | AdamItem[] | int tile_begin[]
+    uint16_t* g16_buf = nullptr;
+    const AdamItem* g16_items = nullptr; const int* g16_tb = nullptr; int g16_n_items = 0, g16_tiles = 0;
+    int g_g16 = -1;
     size_t wg_rest_head = 0;             // wg_rest[0, wg_rest_head) belong to part 0
     hipGraphExec_t gexec_part[2] = {nullptr, nullptr};
     float gp_ls[2] = {0.f, 0.f}; int gp_cw[2] = {-1, -1}, gp_norm[2] = {-1, -1}, gp_fresh[2] = {-1, -1};
@@ -292,6 +300,7 @@ struct m2f_plan {
         if (gexec) (void)hipGraphExecDestroy(gexec);
         for (hipGraphExec_t g : gexec_part) if (g) (void)hipGraphExecDestroy(g);
         if (fused_dev) (void)hipFree(fused_dev);
+        if (g16_dev) (void)hipFree(g16_dev);
     }
 };
 
@@ -1421,6 +1430,7 @@ int do_backward(m2f_plan& P, hipStream_t s) {
         for (const CastBatch& cb : P.wg_casts) M2F_HIP(m2f_launch_cast(cb, s));
         if (g_prof) { g_prof->end(); g_prof->begin(M2F_LAYOUT_TN, P.wg_flops); }
         if (P.fused_on) M2F_HIP(m2f_p8_launch_table_rc_adam(P.wg_tab_adam, s));      // dW stays in registers: Adam in the epilogue
+        else if (P.g16_on) M2F_HIP(m2f_launch_gemm_table(P.wg_tab_g16, s));            // dW leaves as bf16 (the bf16 gradient exchange's buffer)
         else M2F_HIP(m2f_launch_gemm_table(P.wg_tab, s));
         if (g_prof) g_prof->end();
         if (int r = run_launches(P, P.wg_rest, s)) return r;
@@ -1430,6 +1440,11 @@ int do_backward(m2f_plan& P, hipStream_t s) {
     for (const LnReduceBatch& rb : P.lnred) {
         if (g_prof) g_prof->begin(9, 0.0);
         M2F_HIP(m2f_launch_ln_param_reduce(rb, s));
+        if (g_prof) g_prof->end();
+    }
+    if (P.g16_on && !P.fused_on) {                     // ... and every other gradient rounded into the bf16 buffer
+        if (g_prof) g_prof->begin(10, 0.0);
+        M2F_HIP(m2f_launch_cast_items(P.grads, P.g16_buf, P.g16_items, P.g16_tb, P.g16_n_items, P.g16_tiles, s));
         if (g_prof) g_prof->end();
     }
     if (P.fused_on) {                                  // every gradient the table launch did not consume: biases, LayerNorm, wg_rest's matrices
@@ -1675,6 +1690,60 @@ int m2f_adam_step_shadowed(const m2f_config* cfg, float* params, const float* gr
                                         weight_decay, step, grad_scale_ptr, stream);
 }
 
+namespace {
+// The table's problems with their parameter-shadow pointers (res / gate / ldres / ldgate: the Adam epilogue's; `shadow` may be null) and the
+// optimizer-table items the table does NOT cover (1-D parameters, matrices of wg_rest), re-tiled from 0.  Fails when a problem is not a block
+// of one 2-D parameter or a parameter is only partly covered.
+int table_coverage(m2f_plan& P, uint16_t* param_shadow, std::vector<GemmProblem>& tp, std::vector<AdamItem>& items, std::vector<int>& tb, int& tiles) {
+    AdamTable at;
+    if (adam_table(P.cfg, at)) return 1;
+    // every table problem writes a block of whole rows of ONE 2-D parameter's gradient: find the tensor, its shadows, the first row
+    tp = P.tprobs_host;
+    std::vector<long long> covered(P.pm.mats.size(), 0);
+    for (GemmProblem& q : tp) {
+        const long long e = q.c - P.grads;
+        size_t mi = P.pm.mats.size();
+        for (size_t i = 0; i < P.pm.mats.size(); ++i) {
+            const ParamMap::Mat& m = P.pm.mats[i];
+            if (e >= (long long)m.off && e < (long long)m.off + (long long)m.rows * m.cols) { mi = i; break; }
+        }
+        if (mi == P.pm.mats.size()) return fail("weight-gradient table coverage: a weight-gradient problem does not write a 2-D parameter's gradient");
+        const ParamMap::Mat& m = P.pm.mats[mi];
+        const long long rel = e - (long long)m.off;
+        // (a block of rows r0.. x columns c0.. of the parameter: whole matrices, the q / k / v row blocks of a fusion layer's in-projection,
+        //  the column halves of a Linear over a never-materialised torch.cat)
+        const int r0 = (int)(rel / m.cols), c0 = (int)(rel % m.cols), ldd = (m.cols + 7) & ~7, ldt = (m.rows + 7) & ~7;
+        if (q.ldc != m.cols || c0 + q.N > m.cols || r0 + q.M > m.rows || q.res || q.gate)
+            return fail("weight-gradient table coverage: a weight-gradient problem is not a block of its parameter");
+        q.res = param_shadow ? reinterpret_cast<const float*>(param_shadow + m.soff + (size_t)r0 * ldd + c0) : nullptr;
+        q.gate = param_shadow ? reinterpret_cast<const float*>(param_shadow + m.soff_t + (size_t)c0 * ldt + r0) : nullptr;
+        q.ldres = ldd; q.ldgate = ldt;
+        covered[mi] += (long long)q.M * q.N;
+    }
+    // what is left for the shadow-writing Adam kernel: every item of the optimizer's tensor table except the fully covered matrices
+    items.clear(); tb.clear(); tiles = 0;
+    for (const AdamItem& it0 : at.items) {
+        bool fused = false;
+        if (it0.rows > 0)
+            for (size_t i = 0; i < P.pm.mats.size(); ++i)
+                if ((long long)P.pm.mats[i].off == it0.off) {
+                    const long long all = (long long)P.pm.mats[i].rows * P.pm.mats[i].cols;
+                    if (covered[i] == all) fused = true;
+                    else if (covered[i] != 0) return fail("weight-gradient table coverage: a parameter is only partly covered by the weight-gradient table");
+                }
+        if (fused) continue;
+        AdamItem it = it0;
+        it.tile_begin = tiles;
+        tb.push_back(tiles);
+        tiles += it.rows > 0 ? ((it.rows + 63) / 64) * it.tiles_c : (it.cols + 4095) / 4096;
+        items.push_back(it);
+    }
+    tb.push_back(tiles);
+    if (items.empty() || items.size() > M2F_ADAM_MAX_ITEMS) return fail("weight-gradient table coverage: no / too many residual tensors");
+    return 0;
+}
+}  // namespace
+
 /* Optimizer inside the step (round 4).  See include/m2fnet_hip.h. */
 int m2f_plan_fused_adam_setup(m2f_plan* plan, float* params, float* exp_avg, float* exp_avg_sq, uint16_t* param_shadow,
                               const float* hyper_dev, const float* grad_scale_ptr) {
@@ -1686,53 +1755,11 @@ int m2f_plan_fused_adam_setup(m2f_plan* plan, float* params, float* exp_avg, flo
     if (!P.ext_wshadow || P.ext_wshadow != param_shadow) return fail("m2f_plan_fused_adam_setup: the plan must share the model's parameter-shadow buffer (m2f_plan_create_shared)");
     if (!params || !exp_avg || !exp_avg_sq || !hyper_dev) return fail("m2f_plan_fused_adam_setup: NULL buffer");
     if (params != P.params) return fail("m2f_plan_fused_adam_setup: `params` is not the plan's parameter buffer");
-    AdamTable at;
-    if (adam_table(P.cfg, at)) return 1;
-    // every table problem writes a block of whole rows of ONE 2-D parameter's gradient: find the tensor, its shadows, the first row
-    std::vector<GemmProblem> tp = P.tprobs_host;
-    std::vector<long long> covered(P.pm.mats.size(), 0);
-    for (GemmProblem& q : tp) {
-        const long long e = q.c - P.grads;
-        size_t mi = P.pm.mats.size();
-        for (size_t i = 0; i < P.pm.mats.size(); ++i) {
-            const ParamMap::Mat& m = P.pm.mats[i];
-            if (e >= (long long)m.off && e < (long long)m.off + (long long)m.rows * m.cols) { mi = i; break; }
-        }
-        if (mi == P.pm.mats.size()) return fail("m2f_plan_fused_adam_setup: a weight-gradient problem does not write a 2-D parameter's gradient");
-        const ParamMap::Mat& m = P.pm.mats[mi];
-        const long long rel = e - (long long)m.off;
-        // (a block of rows r0.. x columns c0.. of the parameter: whole matrices, the q / k / v row blocks of a fusion layer's in-projection,
-        //  the column halves of a Linear over a never-materialised torch.cat)
-        const int r0 = (int)(rel / m.cols), c0 = (int)(rel % m.cols), ldd = (m.cols + 7) & ~7, ldt = (m.rows + 7) & ~7;
-        if (q.ldc != m.cols || c0 + q.N > m.cols || r0 + q.M > m.rows || q.res || q.gate)
-            return fail("m2f_plan_fused_adam_setup: a weight-gradient problem is not a block of its parameter");
-        q.res = reinterpret_cast<const float*>(param_shadow + m.soff + (size_t)r0 * ldd + c0);
-        q.gate = reinterpret_cast<const float*>(param_shadow + m.soff_t + (size_t)c0 * ldt + r0);
-        q.ldres = ldd; q.ldgate = ldt;
-        covered[mi] += (long long)q.M * q.N;
-    }
-    // what is left for the shadow-writing Adam kernel: every item of the optimizer's tensor table except the fully covered matrices
+    std::vector<GemmProblem> tp;
     std::vector<AdamItem> items;
     std::vector<int> tb;
     int tiles = 0;
-    for (const AdamItem& it0 : at.items) {
-        bool fused = false;
-        if (it0.rows > 0)
-            for (size_t i = 0; i < P.pm.mats.size(); ++i)
-                if ((long long)P.pm.mats[i].off == it0.off) {
-                    const long long all = (long long)P.pm.mats[i].rows * P.pm.mats[i].cols;
-                    if (covered[i] == all) fused = true;
-                    else if (covered[i] != 0) return fail("m2f_plan_fused_adam_setup: a parameter is only partly covered by the weight-gradient table");
-                }
-        if (fused) continue;
-        AdamItem it = it0;
-        it.tile_begin = tiles;
-        tb.push_back(tiles);
-        tiles += it.rows > 0 ? ((it.rows + 63) / 64) * it.tiles_c : (it.cols + 4095) / 4096;
-        items.push_back(it);
-    }
-    tb.push_back(tiles);
-    if (items.empty() || items.size() > M2F_ADAM_MAX_ITEMS) return fail("m2f_plan_fused_adam_setup: no / too many residual tensors");
+    if (int r = table_coverage(P, param_shadow, tp, items, tb, tiles)) return r;
     const size_t o_tab = 256, o_items = o_tab + ((tp.size() * sizeof(GemmProblem) + 255) & ~(size_t)255),
                  o_tb = o_items + ((items.size() * sizeof(AdamItem) + 255) & ~(size_t)255), bytes = o_tb + tb.size() * sizeof(int) + 256;
     if (P.fused_dev) { (void)hipFree(P.fused_dev); P.fused_dev = nullptr; }
@@ -1751,6 +1778,47 @@ int m2f_plan_fused_adam_setup(m2f_plan* plan, float* params, float* exp_avg, flo
     P.fz_items = reinterpret_cast<const AdamItem*>(d + o_items); P.fz_tb = reinterpret_cast<const int*>(d + o_tb);
     P.fz_n_items = (int)items.size(); P.fz_tiles = tiles;
     P.fused_ready = true;
+    return 0;
+}
+
+/* Gradients left as bf16 (round 4).  See include/m2fnet_hip.h. */
+int m2f_plan_grad_bf16(m2f_plan* plan, uint16_t* grads_bf16) {
+    if (!plan) return fail("m2f_plan_grad_bf16: NULL plan (destroyed?)");
+    m2f_plan& P = *plan;
+    if (!grads_bf16) { P.g16_on = false; return 0; }
+    if (!P.train || !P.grads || P.prec != M2F_PREC_BF16 || !P.wg_nt || P.wg_tab.table_tile != 132 || P.tprobs_host.empty())
+        return fail("m2f_plan_grad_bf16: needs a bf16 train plan whose weight-gradient table runs in the eight-phase form (M2F_TABLE_TILE=132)");
+    if (reinterpret_cast<uintptr_t>(grads_bf16) & 15) return fail("m2f_plan_grad_bf16: 16-byte aligned buffer required");
+    if (!P.g16_ready || P.g16_buf != grads_bf16) {
+        std::vector<GemmProblem> tp;
+        std::vector<AdamItem> items;
+        std::vector<int> tb;
+        int tiles = 0;
+        if (int r = table_coverage(P, nullptr, tp, items, tb, tiles)) return r;
+        tb.clear(); tiles = 0;                               // the cast kernel walks every item as a flat range in tiles of 4,096 elements
+        for (AdamItem& it : items) {
+            it.tile_begin = tiles; tb.push_back(tiles);
+            const long long n = it.rows > 0 ? (long long)it.rows * it.cols : (long long)it.cols;
+            tiles += (int)((n + 4095) / 4096);
+        }
+        tb.push_back(tiles);
+        for (GemmProblem& q : tp) { q.res = reinterpret_cast<const float*>(grads_bf16 + (q.c - P.grads)); q.gate = nullptr; q.ldres = 0; q.ldgate = 0; }
+        const size_t o_items = (tp.size() * sizeof(GemmProblem) + 255) & ~(size_t)255, o_tb = o_items + ((items.size() * sizeof(AdamItem) + 255) & ~(size_t)255),
+                     bytes = o_tb + tb.size() * sizeof(int) + 256;
+        if (P.g16_dev) { (void)hipFree(P.g16_dev); P.g16_dev = nullptr; }
+        M2F_HIP(hipMalloc(&P.g16_dev, bytes));
+        char* d = static_cast<char*>(P.g16_dev);
+        M2F_HIP(hipMemcpy(d, tp.data(), tp.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
+        M2F_HIP(hipMemcpy(d + o_items, items.data(), items.size() * sizeof(AdamItem), hipMemcpyHostToDevice));
+        M2F_HIP(hipMemcpy(d + o_tb, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+        P.wg_tab_g16 = P.wg_tab;
+        P.wg_tab_g16.table = reinterpret_cast<const GemmProblem*>(d);
+        P.g16_items = reinterpret_cast<const AdamItem*>(d + o_items); P.g16_tb = reinterpret_cast<const int*>(d + o_tb);
+        P.g16_n_items = (int)items.size(); P.g16_tiles = tiles;
+        P.g16_buf = grads_bf16; P.g16_ready = true;
+        if (P.gexec) { (void)hipGraphExecDestroy(P.gexec); P.gexec = nullptr; }        // (another buffer: the captured launches hold the old pointers)
+    }
+    P.g16_on = true;
     return 0;
 }
 
@@ -1841,7 +1909,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
     if (!P.train) return fail("m2f_step needs a train plan");
     if (!use_graph || !P.warmed) { P.warmed = true; return step_body(P, label_smoothing, use_class_weights, normalise, s); }
     if (P.gexec && (P.g_ls != label_smoothing || P.g_cw != use_class_weights || P.g_norm != normalise || P.g_fresh != (int)P.params_fresh ||
-                    P.g_fused != (int)P.fused_on)) {
+                    P.g_fused != (int)P.fused_on || P.g_g16 != (int)P.g16_on)) {
         (void)hipGraphExecDestroy(P.gexec);
         P.gexec = nullptr;
     }
@@ -1855,7 +1923,7 @@ int m2f_step(m2f_plan* plan, float label_smoothing, int use_class_weights, int n
         e = hipGraphInstantiate(&P.gexec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { P.gexec = nullptr; return hipfail(e, "hipGraphInstantiate"); }
-        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise; P.g_fresh = (int)P.params_fresh; P.g_fused = (int)P.fused_on;
+        P.g_ls = label_smoothing; P.g_cw = use_class_weights; P.g_norm = normalise; P.g_fresh = (int)P.params_fresh; P.g_fused = (int)P.fused_on; P.g_g16 = (int)P.g16_on;
     }
     M2F_HIP(hipGraphLaunch(P.gexec, s));
     return 0;

@@ -939,6 +939,41 @@ hipError_t m2f_launch_adam_shadowed(float* p, const void* g, int g_is_bf16, floa
     return hipGetLastError();
 }
 
+// fp32 -> bf16 of the flat-buffer ranges of `items` (whole tensors incl. their pads: rows > 0 -> rows x cols elements, else `cols`): the
+// gradients the weight-gradient table launch did NOT write as bf16 itself (biases, LayerNorm, the matrices outside the table) when the
+// step leaves its gradients in a bf16 buffer (m2f_plan_grad_bf16); tiles of 4,096 elements, tile -> item by bisection
+__global__ __launch_bounds__(256) void m2f_cast_items_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, const AdamItem* __restrict__ items,
+                                                            const int* __restrict__ tile_begin, int n_items, int total_tiles) {
+    __shared__ int tb[M2F_ADAM_MAX_ITEMS + 1];
+    for (int i = threadIdx.x; i <= n_items; i += 256) tb[i] = tile_begin[i];
+    __syncthreads();
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        int lo = 0, hi = n_items - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
+        const AdamItem it = items[lo];
+        const long long n = it.rows > 0 ? (long long)it.rows * it.cols : (long long)it.cols;
+        const long long base = (long long)(t - tb[lo]) * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long idx = base + q * 1024 + threadIdx.x * 4;
+            if (idx + 3 < n) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + it.off + idx);
+                uint2 w;
+                w.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
+                w.y = (uint32_t)m2f_bf16_bits(v[2]) | ((uint32_t)m2f_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2*>(dst + it.off + idx) = w;
+            } else {
+                for (int e = 0; e < 4; ++e) if (idx + e < n) dst[it.off + idx + e] = m2f_bf16_bits(src[it.off + idx + e]);
+            }
+        }
+    }
+}
+hipError_t m2f_launch_cast_items(const float* src, uint16_t* dst, const AdamItem* items, const int* tile_begin, int n_items, int total_tiles, hipStream_t stream) {
+    if (n_items < 1 || n_items > M2F_ADAM_MAX_ITEMS || total_tiles < 1 || !items || !tile_begin || !src || !dst) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(m2f_cast_items_kernel, dim3(total_tiles < 2048 ? total_tiles : 2048), dim3(256), 0, stream, src, dst, items, tile_begin, n_items, total_tiles);
+    return hipGetLastError();
+}
+
 // step-dependent factors of the update in device memory (a captured graph cannot take them as kernel arguments): one thread
 __global__ void m2f_adam_hyper_kernel(float* __restrict__ h, float lr_bc1, float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2) {
     h[0] = lr_bc1; h[1] = beta1; h[2] = beta2; h[3] = eps; h[4] = wd; h[5] = inv_sqrt_bc2; h[6] = 0.f; h[7] = 0.f;

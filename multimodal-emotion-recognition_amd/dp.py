@@ -210,6 +210,7 @@ class GradReducer:
                 print(f"mer_amd.dp: bf16 all-reduce unavailable ({e}); using the fp32 gradient exchange", file=sys.stderr)
                 self.exchange = exchange = "fp32"
         self.buf16 = torch.empty(n_params, dtype=torch.bfloat16, device=buf.device) if exchange == "bf16" else None
+        self.buf16_filled = False          # set by the caller per step: the plan wrote buf16 itself (runtime.Plan.grad_bf16), no rounding pass
         self._work = []
         self._starts = None
         self.stub = False
@@ -273,6 +274,8 @@ class GradReducer:
     def zero_contribution(self) -> None:
         """This rank holds no dialogue of the global batch: gradients, denominator and numerator are all zero."""
         self.buf.zero_()
+        if self.buf16 is not None and self.buf16_filled:
+            self.buf16.zero_()
 
     def all_reduce(self, async_op: bool = False) -> None:
         if not dist.is_initialized():
@@ -299,7 +302,8 @@ class GradReducer:
             order = list(reversed(self.param_chunks))
             work = []
             for a, b in order:
-                self.buf16[a:b].copy_(self.buf[a:b])                     # one rounding per rank, on the device
+                if not self.buf16_filled:
+                    self.buf16[a:b].copy_(self.buf[a:b])                 # one rounding per rank, on the device
                 work.append(self._sum(self.buf16[a:b]))
 
             def wait(i):
@@ -405,6 +409,7 @@ class DataParallelStep:
         if overlap is None:
             overlap = os.environ.get("M2F_DP_OVERLAP", "0") == "1"
         self.model, self.optimizer, self.overlap = model, optimizer, bool(overlap)
+        self.grad_bf16 = os.environ.get("M2F_GRAD_BF16", "1") != "0"
         self._split: Optional[int] = None
         eng = model.engine()
         eng.ensure_grad()
@@ -437,6 +442,7 @@ class DataParallelStep:
         eng.stream.wait_stream(cur)
         if B == 0:                                    # empty shard: contribute zeros, but take part in every collective
             with torch.cuda.stream(eng.stream):
+                self.reducer.buf16_filled = (self.reducer.exchange == "bf16" and self.grad_bf16 and not (self.overlap and self.reducer.world() > 1))
                 self.reducer.zero_contribution()
                 eng.publish_grads()
                 # the SAME bucket schedule as the ranks that hold dialogues (number, order and sizes of the collectives)
@@ -455,6 +461,21 @@ class DataParallelStep:
             if class_weights is not None:
                 plan.class_w[: class_weights.numel()].copy_(class_weights)
             split = self.split_for(plan)
+            # bf16 exchange, whole-step form: the step itself leaves every gradient rounded in the exchange buffer (the weight-gradient
+            # launch writes bf16 dW directly: no fp32 dW round trip, no rounding pass over 4 bytes per parameter before the all-reduce)
+            g16 = self.reducer.buf16 if (self.reducer.exchange == "bf16" and split == 0 and self.grad_bf16) else None
+            if g16 is not None and not getattr(plan, "_g16_bad", False):
+                try:
+                    if getattr(plan, "_g16_ref", None) is not g16:
+                        plan.grad_bf16(g16)
+                except Exception:                             # (another table form): the rounding pass stays
+                    plan._g16_bad = True
+                    g16 = None
+            else:
+                g16 = None
+            self.reducer.buf16_filled = g16 is not None
+            if g16 is None and getattr(plan, "_g16_ref", None) is not None:
+                plan.grad_bf16(None)
             if split > 0:
                 cw = class_weights is not None
                 plan.step_part(0, label_smoothing, cw, False, use_graph)              # tail <- (loss, den, num); fusion / classifier gradients final

@@ -105,6 +105,7 @@ SIGNATURES = {
                                   c_int, c_void_p, c_int, c_uint32, c_float, c_void_p, c_void_p]),
     "m2f_attention_probs_elems": (c_int64, [c_int, c_int, c_int]),
     "m2f_set_shadow_map": (c_int, [c_void_p, c_void_p, c_int64]),
+    "m2f_plan_grad_bf16": (c_int, [c_void_p, c_void_p]),
     "m2f_plan_fused_adam_setup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "m2f_plan_fused_adam": (c_int, [c_void_p, c_int]),
     "m2f_adam_hyper": (c_int, [c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
@@ -451,6 +452,11 @@ class Plan:
         check(lib().m2f_plan_fused_adam_setup(self._h(), params.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param_shadow.data_ptr(),
                                               hyper.data_ptr(), ptr(grad_scale)), "m2f_plan_fused_adam_setup")
         self._fused_refs = (params, exp_avg, exp_avg_sq, param_shadow, hyper, grad_scale)      # (the plan holds raw pointers)
+
+    def grad_bf16(self, buf16) -> None:
+        """m2f_plan_grad_bf16: the NEXT steps leave every gradient, rounded once, in `buf16` (bf16 [n_params]; None: back to fp32)."""
+        check(lib().m2f_plan_grad_bf16(self._h(), buf16.data_ptr() if buf16 is not None else None), "m2f_plan_grad_bf16")
+        self._g16_ref = buf16
 
     def fused_adam(self, on: bool) -> None:
         """The NEXT step() also takes the optimizer step (on) / leaves the weight gradients in the gradient buffer (off)."""

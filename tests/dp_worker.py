@@ -162,7 +162,18 @@ def main():
             sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange=exchange, overlap=overlap, algorithm=algorithm)
             losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(3)]
             torch.cuda.synchronize()
-            res["E"][(algorithm, overlap, exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone()}
+            res["E"][(algorithm, overlap, exchange)] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(),
+                                                        "g16": bool(sb.reducer.buf16_filled)}
+    # ... and the bf16 exchange with the rounding pass over the fp32 buffer (M2F_GRAD_BF16=0) instead of bf16 gradients written by the step
+    torch.manual_seed(0)
+    mb = M2FNet(cfg, precision="bf16").to(device).train()
+    mb.load_state_dict({k: v.to(device) for k, v in synth.make_state_dict(cfg).items()})
+    ob = FusedAdam(mb, lr=1e-3, weight_decay=0.01)
+    sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange="bf16", overlap=False)
+    sb.grad_bf16 = False
+    losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(3)]
+    torch.cuda.synchronize()
+    res["E"][("rounding_pass", False, "bf16")] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(), "g16": bool(sb.reducer.buf16_filled)}
 
     # ---- F: the training loop in bf16 mode with the overlapped bf16 exchange: the last global batch leaves rank 1's shard EMPTY,
     # and the empty rank must issue the same collectives (tail, fusion / classifier bucket, encoder buckets) as rank 0 ----------

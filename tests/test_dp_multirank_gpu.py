@@ -111,6 +111,11 @@ def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce(dp2_results):
         assert torch.equal(a["params"], b["params"])
         assert torch.equal(b["params"], r1["E"][("rs_ag", overlap, exchange)]["params"])
         assert a["losses"][-1] < a["losses"][0]
+    # bf16 exchange, whole-step form: the step left its gradients in the exchange buffer itself (m2f_plan_grad_bf16) - same bits as the
+    # rounding pass over the fp32 buffer it replaces
+    a, c = r0["E"][("all_reduce", False, "bf16")], r0["E"][("rounding_pass", False, "bf16")]
+    assert a["g16"] and not c["g16"]
+    assert a["losses"] == c["losses"] and torch.equal(a["params"], c["params"])
 
 
 def test_empty_shard_follows_the_overlapped_bucket_schedule(dp2_results):

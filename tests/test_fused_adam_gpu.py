@@ -108,3 +108,35 @@ def test_matrix_gradients_are_not_written_by_the_fused_step():
             assert torch.equal(g, ref[k]) or g.dim() == 2, k       # (1-D gradients: the same bits as the unfused step's)
             written += 1
     assert untouched >= 10 and written >= 10, (untouched, written)
+
+
+@pytest.mark.parametrize("name", ["tiny_ragged", "c2_slice", "c3_slice_l16", "tiny_shared_norm"])
+def test_gradients_left_as_bf16_equal_the_rounded_fp32_gradients(name):
+    """m2f_plan_grad_bf16 (the data-parallel bf16 exchange's buffer filled by the step itself): the weight-gradient launch writes its dW as
+    bf16, one cast launch rounds every other gradient - element for element the bits of rounding a plain step's fp32 gradients, with the
+    eager and the captured step; switching back restores fp32 gradients."""
+    cfg, B, L, lengths, kind = synth.CASES[name]
+    batch = [t.cuda() for t in synth.make_inputs(cfg, B, L, lengths, kind)]
+    m = _model(cfg)
+    m.train_step(*batch, use_graph=False)
+    eng = m.engine()
+    plan = next(iter(eng.plans.values()))
+    g32 = eng.flat_grad.detach().clone()
+    want = g32.to(torch.bfloat16)
+    real = torch.zeros(g32.numel(), dtype=torch.bool, device="cuda")
+    for (_, o, n, _) in eng.items:
+        real[o: o + n] = True
+    buf16 = torch.zeros(g32.numel(), dtype=torch.bfloat16, device="cuda")
+    plan.grad_bf16(buf16)
+    for use_graph in (False, True, True):
+        buf16.zero_()
+        eng.flat_grad.fill_(3.0)
+        m.train_step(*batch, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert torch.equal(buf16[real].view(torch.int16), want[real].view(torch.int16)), use_graph
+    n_untouched = sum(1 for (p, o, n, s) in eng.items if len(s) == 2 and bool((eng.flat_grad[o: o + n] == 3.0).all()))
+    assert n_untouched >= 4                                        # the table's matrices: no fp32 dW was written
+    plan.grad_bf16(None)
+    m.train_step(*batch, use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat_grad[real], g32[real])

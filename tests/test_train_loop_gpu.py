@@ -281,7 +281,7 @@ def test_training_loop_with_in_loop_text_encoder(tmp_path, monkeypatch):
     model = tr.M2FNet(cfg.model).to(device)
     enc = tr.build_text_encoder(te_cfg, 64, device)
     object.__setattr__(model, "text_encoder", enc)
-    assert "text_encoder" not in dict(model.named_modules()) and all("text_encoder" not in k for k in model.state_dict())
+    assert "text_encoder" not in dict(model.named_modules()) and not any(k.startswith("text_encoder.") for k in model.state_dict())
     # what move_batch hands to the model: [CLS] rows at valid slots, zeros at pads
     batch = next(iter(dl_val))
     assert batch["text_ids"].shape[:2] == batch["padding_mask"].shape and batch["text_ids"].shape[2] == S

@@ -151,7 +151,7 @@ PARTS = ["encoders", "fusion", "classifier"]
 
 
 def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump="", packed=False,
-                 repeats=1, overlap=False, algorithm="all_reduce", fused_adam=False):
+                 repeats=1, overlap=False, algorithm="all_reduce", fused_adam=False, grad_bf16=True):
     cfg, B, L = wl["cfg"], wl["B"], wl["L"]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=dtype, shape_buckets=False).to(device).train()      # the plan IS the workload's (B, L): no bucket padding
@@ -192,14 +192,15 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
             plan.step(0.1, False, False, use_graph)                     # fwd + CE + bwd (sum-gradient; tail <- den, num)
             stepper.reducer.reduce_and_step(opt)      # RCCL all-reduce buckets (tail first) pipelined with fused Adam
 
-        if world > 1 and not split and stepper.reducer.exchange == "bf16" and stepper.grad_bf16:
-            # bf16 exchange: the step leaves its gradients rounded in the exchange buffer itself (the weight-gradient launch writes bf16 dW:
-            # no fp32 dW round trip and no rounding pass before the all-reduce)
-            try:
-                plan.grad_bf16(stepper.reducer.buf16)
-                stepper.reducer.buf16_filled = True
-            except runtime.HipError:
-                stepper.reducer.buf16_filled = False
+        if world > 1:
+            # bf16 exchange: the plan was created before the stepper pointed the engine at the exchange buffer - arm it now
+            eng._arm_grad_bf16(plan)
+            stepper.reducer.buf16_filled = (not split) and stepper.reducer.buf16 is not None and getattr(plan, "_g16_ref", None) is stepper.reducer.buf16
+        g16_on = False
+        if world == 1 and grad_bf16 and dtype == "bf16":
+            # N = 1 with the gradient precision of the bf16 exchange at N > 1: rounded once to bf16 by the step (the weight-gradient launch
+            # writes bf16 dW), read as bf16 by the optimizer - no fp32 dW round trip
+            g16_on = model.set_grad_bf16(True)
         eng.publish_grads()
         for _ in range(max(warmup, 3)):                # >= 3: eager warm-up, graph capture, first replay
             one_step()
@@ -269,6 +270,18 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         # ---- secondary figure: forward + criterion + backward only (SURVEY 8-d's strict metric; `value` above also
         # pays for the optimizer and, at N > 1, the gradient exchange) ---------------------------------------------
         n_fb = max(10, min(steps, 50))
+        fp32_grad_ms = None
+        if g16_on:
+            # ... and the same step with fp32 gradients (rounds 1-3), on the same clock, beside it
+            model.set_grad_bf16(False)
+            for _ in range(3):
+                one_step()
+            side.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(steps):
+                one_step()
+            side.synchronize()
+            fp32_grad_ms = (time.perf_counter() - tg0) / steps * 1e3
         for _ in range(3):
             plan.step(0.1, False, False, use_graph)
         side.synchronize()
@@ -332,6 +345,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                    "d_text": c.d_text, "d_audio": c.d_audio, "d_fam": c.d_fam, "params": layout.param_count(c),
                    "step": (("fwd+CE+bwd+Adam (1 hipGraph: the weight-gradient launch applies the optimizer in its epilogue)" if fused_steps[0] else "fwd+CE+bwd (1 hipGraph)") if not split else "fwd+CE+bwd in two hipGraphs") +
                            (f" + {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} grad all-reduce ({stepper.reducer.exchange}" + (", fusion / classifier bucket sent under the encoders' backward)" if split else ")") if world > 1 else "") + ("" if fused_steps[0] else " + fused Adam"),
+                   "gradients": ("bf16 (rounded once by the step; fp32 moments, fp32 master parameters)" if g16_on or (world > 1 and stepper.reducer.exchange == "bf16") else "fp32"),
                    "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                    "launches_per_step": plan.num_launches(),
                    "token_rows": plan.T, "plan_shape": [plan.B, plan.L], "packed": bool(plan.packed),
@@ -344,6 +358,9 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                     "note": "`value` / `ms_per_step` are the first bracket; the others repeat it back to back"},
         "fwd_bwd_only": {"ms_per_step": fb_sec * 1e3, "utterances_per_s_rank0": n_valid / fb_sec, "steps": n_fb,
                          "note": "fwd + CE + bwd graph replays on rank 0, optimizer and gradient exchange excluded"},
+        "fp32_gradients": None if fp32_grad_ms is None else {"ms_per_step": fp32_grad_ms, "value": n_valid / (fp32_grad_ms * 1e-3), "steps": steps,
+                                                               "note": "the same step with fp32 gradients between backward and optimizer (M2FNet.set_grad_bf16(False)); "
+                                                                       "`value` runs with gradients rounded once to bf16, as under the bf16 exchange at N > 1"},
         "step_tflops": slots_per_s * fb_per_slot / 1e12,
         "step_frac_of_peak": slots_per_s * fb_per_slot / 1e12 / (peak * world),
     }
@@ -411,6 +428,10 @@ def main():
                          "parameters).  OFF by default: measured SLOWER at C3 (fused launch 897 us against 243 + 556 us for table launch + "
                          "optimizer kernel, profiles/r04_dev_fused_adam_ab.txt) - tile-shaped 64-byte-per-row accesses to p / m / v reach "
                          "4.2 TB/s where the linear optimizer kernel streams 6.0")
+    ap.add_argument("--grad-fp32", action="store_true", help="N = 1, bf16: keep fp32 gradients between the step and the optimizer (rounds 1-3).  Default "
+                    "since round 4: the step leaves its gradients rounded once to bf16 - the precision every rank's gradient has under the bf16 "
+                    "exchange at N > 1 - and the optimizer reads those (no fp32 dW round trip); the fp32-gradient step is timed beside it "
+                    "(`fp32_gradients`)")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 parity mode) leg of the same workload")
     ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
                     help="second single-GPU configuration reported under `secondary` (N = 1 only)")
@@ -449,7 +470,7 @@ def main():
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
                        roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed, repeats=max(1, args.repeats),
-                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm, fused_adam=args.fused_adam)
+                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm, fused_adam=args.fused_adam, grad_bf16=not args.grad_fp32)
     if rank == 0:
         out = res
         if world == 1 and args.dtype == "bf16" and not args.no_parity_leg and not args.ragged and not args.packed:

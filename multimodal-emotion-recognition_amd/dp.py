@@ -399,23 +399,27 @@ class DataParallelStep:
     m2f_step(normalise=0) -> tail <- (den, num) -> all-reduce -> fused Adam with grad_scale = global den."""
 
     def __init__(self, model, optimizer, group=None, n_buckets: int = 4, exchange: str = "fp32", overlap: Optional[bool] = None,
-                 algorithm: str = "all_reduce"):
+                 algorithm: str = "all_reduce", grad_bf16: Optional[bool] = None):
         """overlap: with more than one rank, run the step in two parts (runtime.Plan.step_part) and put the all-reduce of the
         fusion stack's / classifier's gradients on the wire before the encoders' backward starts (plans that cannot be split -
         fp32 mode - exchange after the whole backward as before).  None = the environment's M2F_DP_OVERLAP (default OFF: the
         path is verified bit for bit against overlap off through gloo staging, tests/test_dp_multirank_gpu.py, but has not yet
         run on RCCL with two devices - no multi-GPU box has been available to this repository).
-        algorithm: "all_reduce" | "rs_ag" (GradReducer)."""
+        algorithm: "all_reduce" | "rs_ag" (GradReducer).
+        grad_bf16 (bf16 exchange, whole-step form): the step leaves its gradients rounded in the exchange buffer itself
+        (runtime.Plan.grad_bf16) instead of a rounding pass over the fp32 buffer; None = M2F_GRAD_BF16 (default on)."""
         if overlap is None:
             overlap = os.environ.get("M2F_DP_OVERLAP", "0") == "1"
         self.model, self.optimizer, self.overlap = model, optimizer, bool(overlap)
-        self.grad_bf16 = os.environ.get("M2F_GRAD_BF16", "1") != "0"
+        self.grad_bf16 = (os.environ.get("M2F_GRAD_BF16", "1") != "0") if grad_bf16 is None else bool(grad_bf16)
         self._split: Optional[int] = None
         eng = model.engine()
         eng.ensure_grad()
         self.reducer = GradReducer(eng.flat_grad_ext, eng.flat.numel(), group, n_buckets, exchange, algorithm)
         self.reducer.align_to(o for (_, o, _, _) in eng.items)      # buckets of whole tensors: the optimizer keeps the bf16 parameter shadows current
         optimizer.grad_scale = self.reducer.global_den
+        if self.reducer.exchange == "bf16" and self.grad_bf16 and self.reducer.world() > 1 and not self.overlap:
+            eng.grad_bf16_buf = self.reducer.buf16           # train plans leave their gradients, rounded once, in the exchange buffer
 
     def split_for(self, plan) -> int:
         """First element of the flat gradient buffer that is final after part 0 of a step, or 0 when the step is not split.  The
@@ -442,7 +446,7 @@ class DataParallelStep:
         eng.stream.wait_stream(cur)
         if B == 0:                                    # empty shard: contribute zeros, but take part in every collective
             with torch.cuda.stream(eng.stream):
-                self.reducer.buf16_filled = (self.reducer.exchange == "bf16" and self.grad_bf16 and not (self.overlap and self.reducer.world() > 1))
+                self.reducer.buf16_filled = eng.grad_bf16_buf is not None and eng.grad_bf16_buf is self.reducer.buf16
                 self.reducer.zero_contribution()
                 eng.publish_grads()
                 # the SAME bucket schedule as the ranks that hold dialogues (number, order and sizes of the collectives)
@@ -462,20 +466,9 @@ class DataParallelStep:
                 plan.class_w[: class_weights.numel()].copy_(class_weights)
             split = self.split_for(plan)
             # bf16 exchange, whole-step form: the step itself leaves every gradient rounded in the exchange buffer (the weight-gradient
-            # launch writes bf16 dW directly: no fp32 dW round trip, no rounding pass over 4 bytes per parameter before the all-reduce)
-            g16 = self.reducer.buf16 if (self.reducer.exchange == "bf16" and split == 0 and self.grad_bf16) else None
-            if g16 is not None and not getattr(plan, "_g16_bad", False):
-                try:
-                    if getattr(plan, "_g16_ref", None) is not g16:
-                        plan.grad_bf16(g16)
-                except Exception:                             # (another table form): the rounding pass stays
-                    plan._g16_bad = True
-                    g16 = None
-            else:
-                g16 = None
-            self.reducer.buf16_filled = g16 is not None
-            if g16 is None and getattr(plan, "_g16_ref", None) is not None:
-                plan.grad_bf16(None)
+            # launch writes bf16 dW directly: no fp32 dW round trip, no rounding pass over 4 bytes per parameter before the all-reduce) -
+            # the engine arms its train plans with the reducer's buffer (model._Engine._arm_grad_bf16; plans that cannot keep fp32)
+            self.reducer.buf16_filled = split == 0 and self.reducer.buf16 is not None and getattr(plan, "_g16_ref", None) is self.reducer.buf16
             if split > 0:
                 cw = class_weights is not None
                 plan.step_part(0, label_smoothing, cw, False, use_graph)              # tail <- (loss, den, num); fusion / classifier gradients final

@@ -66,6 +66,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._step = 0
         self.grad_scale: Optional[torch.Tensor] = None     # device scalar: g <- g / grad_scale (data parallel)
         self._hyper: Optional[torch.Tensor] = None         # fused steps: lr / bc1, betas, eps, weight decay, 1 / sqrt(bc2) on the device
+        self.grads_bf16: Optional[torch.Tensor] = None     # bf16 [n_params]: step() reads THIS instead of the fp32 gradient buffer (a plan
+                                                           # armed with runtime.Plan.grad_bf16 left its gradients there, rounded once)
 
     def _bind(self):
         eng = self.model.engine()
@@ -101,7 +103,9 @@ class FusedAdam(torch.optim.Optimizer):
         # fast path: the engine published its flat-buffer views as .grad (checked on the two end parameters);
         # otherwise gather foreign .grad tensors into the flat buffer first
         first, last = eng.items[0][0], eng.items[-1][0]
-        if not (first.grad is eng.grad_views[0] and last.grad is eng.grad_views[-1]):
+        if self.grads_bf16 is not None or eng.grad_bf16_buf is not None:      # the step left its gradients rounded to bf16 (M2FNet.set_grad_bf16)
+            flat_grad = self.grads_bf16 if self.grads_bf16 is not None else eng.grad_bf16_buf
+        elif not (first.grad is eng.grad_views[0] and last.grad is eng.grad_views[-1]):
             for (p, o, n, s), view in zip(eng.items, eng.grad_views):
                 if p.grad is None:
                     view.zero_()

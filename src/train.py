@@ -156,6 +156,8 @@ def main(config=None):
     # how train() runs the loop body: (fused m2f_step instead of forward / criterion / backward, as one hipGraph)
     model.step_mode = (bool(_runtime(config, "fused_step", True)), bool(_runtime(config, "use_graph", True)))
     model.fused_optimizer = bool(_runtime(config, "fused_optimizer", False))
+    if bool(_runtime(config, "grad_bf16", False)) and world == 1:
+        model.set_grad_bf16(True)
     te_cfg = _runtime(config, "text_encoder", None)
     if te_cfg and te_cfg.get("enabled", False):
         # BASELINE config C5: the text rows are computed in the loop from token ids (Dataset(token_ids=...)) instead of read from

@@ -169,8 +169,7 @@ def main():
     mb = M2FNet(cfg, precision="bf16").to(device).train()
     mb.load_state_dict({k: v.to(device) for k, v in synth.make_state_dict(cfg).items()})
     ob = FusedAdam(mb, lr=1e-3, weight_decay=0.01)
-    sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange="bf16", overlap=False)
-    sb.grad_bf16 = False
+    sb = dp.DataParallelStep(mb, ob, n_buckets=3, exchange="bf16", overlap=False, grad_bf16=False)
     losses = [float(sb(*shard, use_graph=(i > 0))) for i in range(3)]
     torch.cuda.synchronize()
     res["E"][("rounding_pass", False, "bf16")] = {"losses": losses, "params": mb.flat_parameters().detach().cpu().clone(), "g16": bool(sb.reducer.buf16_filled)}

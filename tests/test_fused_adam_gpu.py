@@ -126,8 +126,8 @@ def test_gradients_left_as_bf16_equal_the_rounded_fp32_gradients(name):
     real = torch.zeros(g32.numel(), dtype=torch.bool, device="cuda")
     for (_, o, n, _) in eng.items:
         real[o: o + n] = True
-    buf16 = torch.zeros(g32.numel(), dtype=torch.bfloat16, device="cuda")
-    plan.grad_bf16(buf16)
+    assert m.set_grad_bf16(True)
+    buf16 = eng.grad_bf16_buf
     for use_graph in (False, True, True):
         buf16.zero_()
         eng.flat_grad.fill_(3.0)
@@ -136,7 +136,37 @@ def test_gradients_left_as_bf16_equal_the_rounded_fp32_gradients(name):
         assert torch.equal(buf16[real].view(torch.int16), want[real].view(torch.int16)), use_graph
     n_untouched = sum(1 for (p, o, n, s) in eng.items if len(s) == 2 and bool((eng.flat_grad[o: o + n] == 3.0).all()))
     assert n_untouched >= 4                                        # the table's matrices: no fp32 dW was written
-    plan.grad_bf16(None)
+    assert not m.set_grad_bf16(False)
     m.train_step(*batch, use_graph=True)
     torch.cuda.synchronize()
     assert torch.equal(eng.flat_grad[real], g32[real])
+
+
+def test_optimizer_reads_the_bf16_gradients_of_the_step():
+    """M2FNet.set_grad_bf16: FusedAdam.step() reads the bf16 buffer the step filled - the parameters after four steps are bit for bit those of
+    rounding the fp32 gradient buffer to bf16 between step and optimizer (m2f_adam_step_g16 on a rounded copy), and close to the fp32-gradient
+    run; the mode switches off again."""
+    cfg, B, L, lengths, kind = synth.CASES["c2_slice"]
+    batch = [t.cuda() for t in synth.make_inputs(cfg, B, L, lengths, kind)]
+
+    def run(mode):
+        m = _model(cfg)
+        opt = FusedAdam(m, lr=1e-3, weight_decay=0.01)
+        if mode == "g16":
+            assert m.set_grad_bf16(True)
+        losses = []
+        for i in range(4):
+            losses.append(float(m.train_step(*batch, use_graph=i > 0)))
+            if mode == "round":
+                opt.grads_bf16 = m.engine().flat_grad.to(torch.bfloat16)
+            opt.step()
+        torch.cuda.synchronize()
+        return losses, m.engine().flat.detach().clone(), m
+    l_g, p_g, m_g = run("g16")
+    l_r, p_r, _ = run("round")
+    l_f, p_f, _ = run("fp32")
+    assert l_g == l_r and torch.equal(p_g, p_r)
+    assert max(abs(a - b) for a, b in zip(l_g, l_f)) < 2e-3 and l_g[-1] < l_g[0]
+    assert not m_g.set_grad_bf16(False)
+    m32 = _model(cfg, "fp32")
+    assert not m32.set_grad_bf16(True)                               # fp32 models keep fp32 gradients

@@ -38,3 +38,27 @@ def test_relu_on_the_a_operand_is_refused_not_ignored():
     c = torch.empty(256, 256, device="cuda")
     with pytest.raises(RuntimeError):
         pb.run(1, 256, 256, 64, a.view(torch.int16), b.view(torch.int16), c, relu_a=1)
+
+
+def test_large_forward_launches_reach_the_eight_phase_kernel_through_the_dispatcher():
+    """The production path of the text encoder's large GEMMs: m2f_gemm (bf16 mode, operands with bf16 shadows, automatic tile choice) hands a
+    forward-form launch of at least 256 tiles of 256 x 256 to the eight-phase kernel (gemm.hip::launch_tile16; the ring-launch counter moves)
+    - bias + GELU + residual, against the fp64 result on the same rounded operands; a launch with a dropout site (not this form's) keeps
+    its ring kernel and still agrees with itself run twice."""
+    import torch
+    import mer_amd  # noqa: F401
+    from mer_amd import functional as F, runtime
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 8192, 2048, 512
+    a = (torch.randn(M, K, generator=g) * 0.5).cuda()
+    b = (torch.randn(N, K, generator=g) * 0.5 + 0.05).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    before = runtime.lib().m2f_gemm_ring_launches()
+    c = F.gemm(a, b, layout=F.NT, precision=runtime.BF16, bias=bias, res=res, relu_out=2, src16=True)
+    torch.cuda.synchronize()
+    assert runtime.lib().m2f_gemm_ring_launches() == before + 1
+    ar, br = a.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
+    ref = torch.nn.functional.gelu(ar @ br.t() + bias.double()) + res.double()
+    err = (c.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 4e-3, err

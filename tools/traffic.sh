@@ -35,7 +35,8 @@ adam_rd, n_ad = avg("FETCH_SIZE", is_adam); adam_wr, _ = avg("WRITE_SIZE", is_ad
 # bytes (padding of the flat buffer ignored: <0.1 %).  The shadow-writing optimizer kernel (bf16 mode, N = 1) also writes W and W^T
 # as bf16: 2 x 2 B for every parameter of a 2-D tensor - all but 0.1 % of them
 shadowed = any("m2f_adam_shadow" in k for k in per["WRITE_SIZE"])
-known_rd, known_wr = 16.0 * n_params, (16.0 if shadowed else 12.0) * n_params
+g16 = any("m2f_adam" in k and "<true>" in k for k in per["FETCH_SIZE"])          # bf16 gradients (bench.py's default since round 4): 2 B instead of 4
+known_rd, known_wr = (14.0 if g16 else 16.0) * n_params, (16.0 if shadowed else 12.0) * n_params
 cal_rd = known_rd / adam_rd if adam_rd else None                # bytes per FETCH_SIZE count incl. the gfx950 1/2 factor
 cal_wr = known_wr / adam_wr if adam_wr else None
 g_rd, n_g = avg("FETCH_SIZE", is_gemm); g_wr, _ = avg("WRITE_SIZE", is_gemm)
@@ -45,7 +46,7 @@ out = {"source_hash": bench_py.source_hash(), "workload": bench["config"]["workl
        "adam_dispatches_counted": n_ad,
        "raw_counter_per_launch": {"gemm_FETCH_SIZE": g_rd, "gemm_WRITE_SIZE": g_wr, "adam_FETCH_SIZE": adam_rd, "adam_WRITE_SIZE": adam_wr},
        "calibration_bytes_per_count": {"FETCH_SIZE": cal_rd, "WRITE_SIZE": cal_wr,
-                                       "note": "fused Adam kernel: 16 B read + %d B written per parameter; FETCH factor includes the gfx950 x2 correction" % (16 if shadowed else 12)},
+                                       "note": "fused Adam kernel: %d B read + %d B written per parameter; FETCH factor includes the gfx950 x2 correction" % (14 if g16 else 16, 16 if shadowed else 12)},
        "gemm_hbm_bytes_per_launch": {"read": g_rd * (cal_rd or 0), "write": g_wr * (cal_wr or 0)},
        "by_kernel_raw": {C: {k: {"sum": v, "n": n} for k, (v, n) in sorted(per[C].items())} for C in per}}
 out["traffic_bytes_per_launch"] = out["gemm_hbm_bytes_per_launch"]["read"] + out["gemm_hbm_bytes_per_launch"]["write"]

@@ -151,7 +151,7 @@ PARTS = ["encoders", "fusion", "classifier"]
 
 
 def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragged, buckets, exchange, roofline=True, dump="", packed=False,
-                 repeats=1, overlap=False, algorithm="all_reduce", fused_adam=False, grad_bf16=True):
+                 repeats=1, overlap=False, algorithm="all_reduce", fused_adam=False, grad_bf16=True, fp32_grad_leg=True):
     cfg, B, L = wl["cfg"], wl["B"], wl["L"]
     torch.manual_seed(0)                               # identical replicas on every rank
     model = M2FNet(cfg, precision=dtype, shape_buckets=False).to(device).train()      # the plan IS the workload's (B, L): no bucket padding
@@ -271,7 +271,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         # pays for the optimizer and, at N > 1, the gradient exchange) ---------------------------------------------
         n_fb = max(10, min(steps, 50))
         fp32_grad_ms = None
-        if g16_on:
+        if g16_on and fp32_grad_leg:
             # ... and the same step with fp32 gradients (rounds 1-3), on the same clock, beside it
             model.set_grad_bf16(False)
             for _ in range(3):
@@ -282,6 +282,9 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                 one_step()
             side.synchronize()
             fp32_grad_ms = (time.perf_counter() - tg0) / steps * 1e3
+            model.set_grad_bf16(True)                      # (what follows measures the default mode again)
+            for _ in range(2):
+                one_step()
         for _ in range(3):
             plan.step(0.1, False, False, use_graph)
         side.synchronize()
@@ -432,6 +435,8 @@ def main():
                     "since round 4: the step leaves its gradients rounded once to bf16 - the precision every rank's gradient has under the bf16 "
                     "exchange at N > 1 - and the optimizer reads those (no fp32 dW round trip); the fp32-gradient step is timed beside it "
                     "(`fp32_gradients`)")
+    ap.add_argument("--no-fp32-grad-leg", action="store_true", help="skip the fp32-gradient step timed beside the default line (profiling runs: every "
+                    "kernel of the run is then the default mode's)")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 parity mode) leg of the same workload")
     ap.add_argument("--secondary", default="c2", choices=sorted(WORKLOADS) + ["none"],
                     help="second single-GPU configuration reported under `secondary` (N = 1 only)")
@@ -470,7 +475,7 @@ def main():
     exchange = args.grad_exchange if args.grad_exchange != "auto" else ("bf16" if args.dtype == "bf16" else "fp32")
     res = run_workload(wl, args.dtype, rank, world, device, args.steps, args.warmup, use_graph, args.ragged, args.buckets, exchange,
                        roofline=True, dump=args.dump_launches if rank == 0 else "", packed=args.packed, repeats=max(1, args.repeats),
-                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm, fused_adam=args.fused_adam, grad_bf16=not args.grad_fp32)
+                       overlap=args.dp_overlap and not args.no_overlap, algorithm=args.dp_algorithm, fused_adam=args.fused_adam, grad_bf16=not args.grad_fp32, fp32_grad_leg=not args.no_fp32_grad_leg)
     if rank == 0:
         out = res
         if world == 1 and args.dtype == "bf16" and not args.no_parity_leg and not args.ragged and not args.packed:

@@ -1268,7 +1268,13 @@ hipError_t launch_tile16(GemmBatch& gb, int tile, hipStream_t stream) {
         // M2F_P8=0 switches it off, M2F_P8_MIN moves the threshold (tiles of 256x256).
         static const int p8_on = getenv("M2F_P8") ? atoi(getenv("M2F_P8")) : 1;
         static const int p8_min = getenv("M2F_P8_MIN") ? atoi(getenv("M2F_P8_MIN")) : 256;
-        if (ring && p8_on && auto_tile && count_tiles(256, 256) >= p8_min && m2f_gemm_p8_ok(gb)) return m2f_p8_launch_kc(gb, stream);
+        // (... and only when those tiles fill whole rounds of the chip: a 256 x 256 tile is ~25 us of work, and 336 of them on 256 CUs -
+        //  the merged QKV projections of the C3 geometry at B = 256 - ran 2 % of the STEP slower than three rounds of 256 x 128 ring tiles)
+        {
+            const int t256 = count_tiles(256, 256);
+            const int rounds = (t256 + 255) / 256;
+            if (ring && p8_on && auto_tile && t256 >= p8_min && t256 * 100 >= 85 * rounds * 256 && m2f_gemm_p8_ok(gb)) return m2f_p8_launch_kc(gb, stream);
+        }
         if (ring && auto_tile && count_tiles(256, 128) >= ring256_min && m2f_gemm_ring256_ok(gb)) return m2f_launch_gemm_ring(gb, 256, 128, stream);
         // (what the 256x128 ring form cannot take - it has bias / ReLU / GELU / residual epilogues only - keeps the register-staged
         // 256x128 build from 1,024 such tiles on: RoBERTa-large geometry 52.3 vs 54.0 ms with 128x128 ring tiles)

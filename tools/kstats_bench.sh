@@ -3,7 +3,7 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; tag=$1; shift
 mkdir -p $R/gpurun_out/ks_$tag
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$tag -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity-leg --repeats 1 "$@" > $R/gpurun_out/ks_$tag/bench.json 2> $R/gpurun_out/ks_$tag/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$tag -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity-leg --no-fp32-grad-leg --repeats 1 "$@" > $R/gpurun_out/ks_$tag/bench.json 2> $R/gpurun_out/ks_$tag/err.txt
 python3 - $R/gpurun_out/ks_$tag <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/p_kernel_stats.csv", recursive=True):

@@ -11,7 +11,7 @@ P5="GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES TCP_TCP_TA_DATA_STALL_CYCLES TA_TA_
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1)); rm -rf /tmp/pb$i
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pb$i -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --no-parity-leg --repeats 1 "$@" > /dev/null 2>/tmp/pb$i.err || { echo "pass $i failed"; tail -3 /tmp/pb$i.err; }
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pb$i -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --no-parity-leg --no-fp32-grad-leg --repeats 1 "$@" > /dev/null 2>/tmp/pb$i.err || { echo "pass $i failed"; tail -3 /tmp/pb$i.err; }
 done
 python3 - "$pat" <<'PY'
 import csv, glob, collections, sys

@@ -10,7 +10,7 @@ tag=$1; shift
 mkdir -p $R/gpurun_out/traffic_$tag
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/traffic_$tag/$C -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --no-parity-leg --repeats 1 "$@" > $R/gpurun_out/traffic_$tag/$C.json 2> $R/gpurun_out/traffic_$tag/$C.err || echo "pass $C failed"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/traffic_$tag/$C -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --no-parity-leg --no-fp32-grad-leg --repeats 1 "$@" > $R/gpurun_out/traffic_$tag/$C.json 2> $R/gpurun_out/traffic_$tag/$C.err || echo "pass $C failed"
 done
 python3 - "$R" "$tag" <<'PY'
 import csv, glob, collections, json, sys

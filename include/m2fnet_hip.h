@@ -216,6 +216,18 @@ int m2f_embed_layernorm(int T, int d, const int64_t* input_ids, const int64_t* p
 int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            const uint8_t* key_pad, float* out, int ldo, m2f_stream_t stream);
 
+/* The same attention on bf16 operands (round 4; the encoder's bf16 mode): q / k / v are the bf16 result of the packed projection
+ * GEMM as it is (leading dimensions in elements; hd, the leading dimensions and the addresses multiples of 8 elements), the products run on
+ * v_mfma_f32_16x16x16_bf16 with fp32 accumulation and an fp32 online softmax, probabilities rounded to bf16 for the P V product (the
+ * denominator sums the rounded values); out16 (bf16) is always written, out32 (fp32, same indexing) when not NULL.  hd <= 128. */
+int m2f_attention_long_fwd_bf16(int B, int S, int H, int hd, const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v,
+                                int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, m2f_stream_t stream);
+
+/* Results of the following m2f_gemm calls of this thread that have a bf16 shadow (m2f_set_shadow_map) have NO fp32 reader: kernels
+ * that know how (the chip-filling bf16 forms) write the shadow only and leave the fp32 buffer untouched; edge tiles and the other
+ * forms still write both.  0 switches it off.  (The plans decide this per buffer from their launch lists: m2f_plan_skipped_copies.) */
+int m2f_set_shadow_only(int on);
+
 /* fp8 GEMM of the in-loop text encoder (BASELINE C5 asks for fp8 MFMA): C[M,N] = act(acc_scale * A8 B8^T + bias) + res with
  * A8 [M,K], B8 [N,K] row-major OCP e4m3 bytes (K, lda, ldb multiples of 16; 16-byte aligned), fp32 accumulate on
  * v_mfma_f32_32x32x16_fp8_fp8; acc_scale = 1 / (scale_a * scale_b) undoes the per-tensor quantisation scales.

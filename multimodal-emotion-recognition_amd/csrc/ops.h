@@ -196,6 +196,9 @@ int m2f_attn_shadow_only_bits(const AttnBatch& ab, int pi, bool bwd);     // hos
 hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
 // Long-sequence forward (S unbounded, hd <= 128): token-level self-attention of the in-loop text encoder (inference).
 // q/k/v rows are token-major (token t = b*S + i), head h in columns [h*hd, (h+1)*hd); key_pad [B, S] (1 = padded, nullable).
+hipError_t m2f_launch_attn_long_fwd_bf16(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
+                                         const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, int B, int S, int H, int hd,
+                                         hipStream_t stream);
 hipError_t m2f_launch_attn_long_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                     const uint8_t* key_pad, float* out, int ldo, int B, int S, int H, int hd, ShadowMap sh,
                                     hipStream_t stream);

@@ -2065,6 +2065,9 @@ int m2f_set_shadow_map(const float* ws_base, uint16_t* shadow, int64_t floats) {
     return 0;
 }
 
+static thread_local int g_shadow_only = 0;
+int m2f_set_shadow_only(int on) { g_shadow_only = on != 0; return 0; }
+
 static void drop_params(float p, uint32_t* thresh, float* scale) {
     *thresh = (uint32_t)std::min(4294967295.0, std::floor((double)p * 4294967296.0));
     *scale = 1.0f / (1.0f - p);
@@ -2084,7 +2087,7 @@ int m2f_gemm(int precision, int layout, int M, int N, int K0, int K1, const floa
     p.bias = bias; p.res = res; p.ldres = ldres; p.gate = gate; p.ldgate = ldgate; p.gate_scale = gate_scale;
     p.bias_grad = bias_grad; p.drop_site = drop_site;
     p.flags = (relu_a ? GF_RELU_A : 0) | (relu_b ? GF_RELU_B : 0) | (relu_out == 1 ? GF_RELU_OUT : 0) |
-              (relu_out == 2 ? GF_GELU_OUT : 0) | (accumulate ? GF_ACCUM : 0);
+              (relu_out == 2 ? GF_GELU_OUT : 0) | (accumulate ? GF_ACCUM : 0) | (g_shadow_only && !accumulate ? GF_NO_F32 : 0);
     p.a.q[0] = a0q; p.a.ldq[0] = ldaq0; p.a.q[1] = a1q; p.a.ldq[1] = ldaq1;
     p.b.q[0] = b0q; p.b.ldq[0] = ldbq0; p.b.q[1] = b1q; p.b.ldq[1] = ldbq1;
     p.a.qt[0] = p.a.qt[1] = p.b.qt[0] = p.b.qt[1] = nullptr;
@@ -2181,6 +2184,15 @@ int m2f_embed_layernorm(int T, int d, const int64_t* input_ids, const int64_t* p
 int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            const uint8_t* key_pad, float* out, int ldo, m2f_stream_t stream) {
     M2F_HIP(m2f_launch_attn_long_fwd(q, ldq, k, ldk, v, ldv, key_pad, out, ldo, B, S, H, hd, g_sh, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int m2f_attention_long_fwd_bf16(int B, int S, int H, int hd, const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v,
+                                int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, m2f_stream_t stream) {
+    if (!q || !k || !v || !out16) return fail("m2f_attention_long_fwd_bf16: NULL operand");
+    if (hd < 8 || hd > 128 || (hd & 7) || ((ldq | ldk | ldv | ldo) & 7))
+        return fail("m2f_attention_long_fwd_bf16: head dim and leading dimensions must be multiples of 8, head dim <= 128");
+    M2F_HIP(m2f_launch_attn_long_fwd_bf16(q, ldq, k, ldk, v, ldv, key_pad, out16, out32, ldo, B, S, H, hd, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -10,6 +10,7 @@ the extractor inside the M2FNet loop); no CPU fallback.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -21,6 +22,10 @@ from .runtime import check, lib, ptr, stream_ptr
 
 def _get(cfg, name, default=None):
     return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name, default)
+
+
+# M2F_ROBERTA_FAT=1: the bf16 mode as rounds 1-3 ran it (every activation as fp32 + bf16, fp32-operand attention) - for A/B measurements
+_FAT_BF16 = os.environ.get("M2F_ROBERTA_FAT", "0") == "1"
 
 
 def _pad8(n: int) -> int:
@@ -128,7 +133,8 @@ class RobertaEncoder(torch.nn.Module):
         w = self._ws.get(key)
         if w is None:
             T, d, Fi = B * S, self.d, self.inter
-            sizes = {"x": T * d, "qkv": T * 3 * d, "ctx": T * d, "t": T * d, "y1": T * d, "h": T * Fi}
+            # ("t" LAST: the bf16 mode leaves it outside the shadow map - its only reader is the LayerNorm kernel, which reads fp32)
+            sizes = {"x": T * d, "qkv": T * 3 * d, "ctx": T * d, "y1": T * d, "h": T * Fi, "t": T * d}
             total = sum((n + 63) // 64 * 64 for n in sizes.values())
             ws = torch.zeros(total, dtype=torch.float32, device=dev)
             ws16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)
@@ -138,7 +144,7 @@ class RobertaEncoder(torch.nn.Module):
                 views[name] = ws[off: off + n].view(T, cols)
                 views16[name] = ws16[off: off + n].view(T, cols)
                 off += (n + 63) // 64 * 64
-            w = {"ws": ws, "ws16": ws16, "v": views, "v16": views16, "stats": torch.empty(T, 2, dtype=torch.float32, device=dev)}
+            w = {"ws": ws, "ws16": ws16, "v": views, "v16": views16, "mapped": total - (T * d + 63) // 64 * 64, "stats": torch.empty(T, 2, dtype=torch.float32, device=dev)}
             if self.fp8:
                 w["q8"] = {n: torch.empty(T, c, dtype=torch.float8_e4m3fn, device=dev) for n, c in (("x", d), ("ctx", d), ("y1", d), ("h", Fi))}
             self._ws[key] = w
@@ -162,8 +168,11 @@ class RobertaEncoder(torch.nn.Module):
         w = self._workspace(B, S, dev)
         v, v16 = w["v"], w["v16"]
         bf16 = prec == runtime.BF16 and not self.fp8
+        # bf16 mode (round 4): the packed projection, the attention context and the FFN hidden activation exist ONLY as bf16 (their one
+        # reader is the next GEMM / the attention kernel, which stage bf16 anyway); the residual stream and the LayerNorm inputs stay fp32
+        lean = bf16 and d % 8 == 0 and hd % 8 == 0 and not _FAT_BF16
         check(lib().m2f_set_shadow_map(ptr(w["ws"]) if bf16 else None, ptr(w["ws16"]) if bf16 else None,
-                                       w["ws"].numel() if bf16 else 0), "m2f_set_shadow_map")
+                                       (w["mapped"] if lean else w["ws"].numel()) if bf16 else 0), "m2f_set_shadow_map")
         try:
             ids = input_ids.reshape(-1).to(torch.int64).contiguous()
             keep = input_ids.ne(self.pad_id).to(torch.int64)
@@ -176,7 +185,7 @@ class RobertaEncoder(torch.nn.Module):
 
             ACT_SCALE = {"x": 16.0, "ctx": 16.0, "y1": 16.0, "h": 8.0}
 
-            def linear(a_name, wkey, L, out, bias, res=None, act=0, out8=None):
+            def linear(a_name, wkey, L, out, bias, res=None, act=0, out8=None, out16_only=False):
                 if self.fp8:
                     sa = ACT_SCALE[a_name]
                     q8 = w["q8"][a_name]
@@ -185,18 +194,30 @@ class RobertaEncoder(torch.nn.Module):
                     F.gemm_fp8(q8, L[wkey + "8"], 1.0 / (sa * L[wkey + "8s"]), bias=bias, res=res, activation=act, out=out,
                                out8=w["q8"][out8] if out8 else None, out8_scale=ACT_SCALE[out8] if out8 else 1.0)
                 else:
-                    F.gemm(v[a_name], L[wkey], F.NT, prec, bias=bias, res=res, relu_out=act, out=out,
-                           shadows=(v16[a_name], None, L[wkey + "16"], None) if bf16 else None)
+                    if lean and out16_only:
+                        check(lib().m2f_set_shadow_only(1), "m2f_set_shadow_only")
+                    try:
+                        F.gemm(v[a_name], L[wkey], F.NT, prec, bias=bias, res=res, relu_out=act, out=out,
+                               shadows=(v16[a_name], None, L[wkey + "16"], None) if bf16 else None)
+                    finally:
+                        if lean and out16_only:
+                            check(lib().m2f_set_shadow_only(0), "m2f_set_shadow_only")
             for L in self._packed:
-                linear("x", "wqkv", L, v["qkv"], L["bqkv"])
-                qkv = v["qkv"]
-                check(lib().m2f_attention_long_fwd(B, S, H, hd, ptr(qkv), 3 * d, qkv.data_ptr() + 4 * d, 3 * d,
-                                                   qkv.data_ptr() + 8 * d, 3 * d, ptr(key_pad), ptr(v["ctx"]), d, stream_ptr()),
-                      "m2f_attention_long_fwd")
+                linear("x", "wqkv", L, v["qkv"], L["bqkv"], out16_only=True)
+                if lean:
+                    q16 = v16["qkv"]
+                    check(lib().m2f_attention_long_fwd_bf16(B, S, H, hd, ptr(q16), 3 * d, q16.data_ptr() + 2 * d, 3 * d,
+                                                            q16.data_ptr() + 4 * d, 3 * d, ptr(key_pad), ptr(v16["ctx"]), None, d,
+                                                            stream_ptr()), "m2f_attention_long_fwd_bf16")
+                else:
+                    qkv = v["qkv"]
+                    check(lib().m2f_attention_long_fwd(B, S, H, hd, ptr(qkv), 3 * d, qkv.data_ptr() + 4 * d, 3 * d,
+                                                       qkv.data_ptr() + 8 * d, 3 * d, ptr(key_pad), ptr(v["ctx"]), d, stream_ptr()),
+                          "m2f_attention_long_fwd")
                 linear("ctx", "wo", L, v["t"], L["bo"], res=v["x"])
                 check(lib().m2f_layernorm_fwd(T, d, ptr(v["t"]), ptr(L["g1"]), ptr(L["b1"]), None, ptr(v["y1"]), ptr(w["stats"]),
                                               self.eps, stream_ptr()), "m2f_layernorm_fwd")
-                linear("y1", "wi", L, v["h"], L["bi"], act=2, out8="h" if self.fp8 else None)
+                linear("y1", "wi", L, v["h"], L["bi"], act=2, out8="h" if self.fp8 else None, out16_only=True)
                 linear("h", "wo2", L, v["t"], L["bo2"], res=v["y1"])
                 check(lib().m2f_layernorm_fwd(T, d, ptr(v["t"]), ptr(L["g2"]), ptr(L["b2"]), None, ptr(v["x"]), ptr(w["stats"]),
                                               self.eps, stream_ptr()), "m2f_layernorm_fwd")

@@ -131,3 +131,71 @@ def test_fp8_text_encoder_cost_in_downstream_logits():
 
 
 FP8_LOGIT_BOUNDS = {"bf16": 5e-2, "fp8": 0.3}
+
+
+# ---- round 4: the attention kernel of the encoder's bf16 mode (csrc/attention_long.hip) against an fp32 softmax(QK^T)V of the SAME
+# bf16-rounded operands.  What differs: probabilities rounded to bf16 before the P V product (relative 2^-9 each, averaged over the
+# keys) and the bf16 rounding of the result itself (2^-9 relative) -> 1.5e-2 of the largest |value| stated, ~4e-3 observed.
+ATTN_BF16_TOL = 1.5e-2
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(3, 64, 4, 64), (2, 100, 2, 32), (2, 130, 3, 16), (1, 200, 2, 128), (2, 37, 2, 24), (2, 64, 1, 8),
+                                      (4, 1, 2, 64)])
+def test_bf16_attention_kernel_matches_fp32_softmax_of_the_same_operands(B, S, H, hd):
+    import ctypes
+    from mer_amd import runtime
+    g = torch.Generator().manual_seed(S * 131 + hd)
+    d = H * hd
+    qkv = (torch.randn(B * S, 3 * d, generator=g) * 1.5).cuda().to(torch.bfloat16)      # the packed projection's layout: q | k | v columns
+    lengths = [max(1, S - 7 * b) for b in range(B)]
+    if B > 2:
+        lengths[-1] = 0                                                                  # a sequence with every key padded -> zero rows
+    key_pad = torch.ones(B, S, dtype=torch.uint8)
+    for b, n in enumerate(lengths):
+        key_pad[b, :n] = 0
+    key_pad = key_pad.cuda()
+    out16 = torch.full((B * S, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out32 = torch.full((B * S, d), float("nan"), dtype=torch.float32, device="cuda")
+    for o32 in (None, out32):
+        runtime.check(runtime.lib().m2f_attention_long_fwd_bf16(B, S, H, hd, qkv.data_ptr(), 3 * d, qkv.data_ptr() + 2 * d, 3 * d,
+                                                                qkv.data_ptr() + 4 * d, 3 * d, key_pad.data_ptr(), out16.data_ptr(),
+                                                                o32.data_ptr() if o32 is not None else None, d, runtime.stream_ptr()),
+                      "m2f_attention_long_fwd_bf16")
+    torch.cuda.synchronize()
+    f = qkv.float().view(B, S, 3, H, hd)
+    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))                         # [B, H, S, hd]
+    sc = q @ k.transpose(-1, -2) / hd ** 0.5
+    sc = sc.masked_fill(key_pad.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(sc, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)                                                     # (all keys padded)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, d)
+    top = ref.abs().max().item()
+    assert torch.isfinite(out16.float()).all() and torch.isfinite(out32).all()
+    assert (out32 - ref).abs().max().item() < ATTN_BF16_TOL * top, (out32 - ref).abs().max().item() / top
+    assert (out16.float() - ref).abs().max().item() < ATTN_BF16_TOL * top, (out16.float() - ref).abs().max().item() / top
+    assert torch.equal(out16, out32.to(torch.bfloat16))                                  # one result, two roundings of it
+    if B > 2:
+        assert out16.view(B, S, d)[-1].float().abs().max().item() == 0.0
+    print(f"bf16 attention B={B} S={S} H={H} hd={hd}: max |d| / max |ref| = {(out16.float() - ref).abs().max().item() / top:.2e}")
+
+
+def test_bf16_mode_lean_and_fat_data_flows_agree():
+    """The bf16 mode with bf16-only projections / context / hidden activations (round 4) against the same mode keeping every
+    activation as fp32 + bf16 with the fp32-operand attention kernel (rounds 1-3): same weights, same tokens."""
+    import mer_amd.roberta as R
+    c, B, S, lengths = SR.CASES["roberta_base_width"]
+    ids, mask = SR.make_batch(c, B, S, lengths)
+    m = _enc(c, "bf16")
+    lean = m(ids.cuda(), mask.cuda()).cpu()
+    old = R._FAT_BF16
+    R._FAT_BF16 = True
+    try:
+        fat = m(ids.cuda(), mask.cuda()).cpu()
+    finally:
+        R._FAT_BF16 = old
+    ref = RO.forward(SR.make_state_dict(c), c, ids, mask)
+    e_lean = (lean - ref)[mask.bool()].abs()
+    e_fat = (fat - ref)[mask.bool()].abs()
+    print(f"bf16 text encoder vs oracle: lean max {e_lean.max():.3e} mean {e_lean.mean():.3e}; fat max {e_fat.max():.3e} mean {e_fat.mean():.3e}")
+    assert e_lean.max().item() < 6e-2 and e_lean.mean().item() < 1e-2
+    assert e_lean.mean().item() < 1.5 * e_fat.mean().item() + 1e-4

@@ -90,8 +90,12 @@ __device__ __forceinline__ P8Desc p8_desc(const GemmBatch& gb, int bpos) {
         D.pi = ring_problem_of(gb, bpos);
         const GemmHot& H = gb.hot[D.pi];
         D.aq = H.aq[0]; D.bq = H.bq[0]; D.M = H.M; D.N = H.N; D.K = H.k[0]; D.lda = H.ldaq[0]; D.ldb = H.ldbq[0]; D.flags = H.flags;
-        const int tl = bpos - H.tile_begin, tiles_m = (H.M + P8Cfg::BM - 1) / P8Cfg::BM;
-        D.m0 = (tl % tiles_m) * P8Cfg::BM; D.n0 = (tl / tiles_m) * P8Cfg::BN;
+        // tile order inside a problem: bands of 8 tile rows, m fastest inside a band - 32 consecutive tiles (what one XCD's 32 workgroups
+        // hold at a time: ring_xcd_remap) are 8 row panels x 4 column panels, 12 operand panels through that L2 instead of the 33 of a
+        // plain m-fastest order
+        const int tl = bpos - H.tile_begin, tiles_m = (H.M + P8Cfg::BM - 1) / P8Cfg::BM, tiles_n = (H.N + P8Cfg::BN - 1) / P8Cfg::BN;
+        const int band = tl / (8 * tiles_n), rem = tl - band * 8 * tiles_n, rows = tiles_m - 8 * band < 8 ? tiles_m - 8 * band : 8;
+        D.m0 = (8 * band + rem % rows) * P8Cfg::BM; D.n0 = (rem / rows) * P8Cfg::BN;
     }
     return D;
 }

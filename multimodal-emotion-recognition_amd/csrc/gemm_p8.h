@@ -111,6 +111,13 @@ __device__ unsigned long long m2f_p8_dbg[64];
 #define P8_ACC(p) do {} while (0)
 #endif
 
+// rows of 16 lanes [x0 x1 x2 x3], [y0 y1 y2 y3]  ->  [x0 x2 y0 y2], [x1 x3 y1 y3]   (v_permlane32_swap, then v_permlane16_swap)
+__device__ __forceinline__ void p8_swap2(uint32_t& x, uint32_t& y) {
+    auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    auto q = __builtin_amdgcn_permlane16_swap(r[0], r[1], false, false);
+    x = q[0]; y = q[1];
+}
+
 // torch.optim.Adam's update of four consecutive elements: the arithmetic of rowops.hip::adam4, contractions spelled out the same way
 // (every optimizer kernel must produce the same bits: tests/test_shared_shadows_gpu.py compares the trajectories)
 __device__ __forceinline__ void p8_adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float gs, float lr_bc1, float beta1,
@@ -310,8 +317,9 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
     int par = 0;                                                                       // buffer of the next k-tile to multiply
 #ifdef P8_TIMING
     unsigned long long tacc[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, tk = 0, tep = 0;
+    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0, tb5 = 0, ntile = 0;      // whole k-tiles by their index inside an output tile
 #endif
-    int ep_relax = 0;                                  // vector-memory instructions the LAST epilogue is known to have issued (0, 32 or >= 57)
+    int ep_relax = 0;                                  // vector-memory instructions (stores) the LAST epilogue left behind it: 0, 16, 32, 48; anything else: 57 or more
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3;
 #pragma unroll 1
@@ -457,7 +465,9 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
             // which were issued between A1 of the next k-tile (below) and those three: loads and stores share ONE in-order counter, and
             // waiting for 256 KiB of stores here would stall the MFMA pipe for thousands of cycles
             if (relax == 0) ring_wait_vm<6>();
+            else if (relax == 16) ring_wait_vm<22>();
             else if (relax == 32) ring_wait_vm<38>();
+            else if (relax == 48) ring_wait_vm<54>();
             else ring_wait_vm<63>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -475,7 +485,14 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
         };
         // (a copy of the LOOP per option set the weight-gradient table uses - plan.hip sets GF_RELU_B only: the FAM layer's
         //  relu(cat(x, text)) operand - ReLU on A has no copy: the launchers refuse it)
+#ifdef P8_TIMING
+#define P8_LOOP(MASK) do { _Pragma("unroll 1") for (int kt = 0; kt < nk; ++kt) { unsigned long long tq0, tq1; P8_STAMP(tq0);                    \
+        ktile(par, std::integral_constant<int, MASK>{}, kt == 0 ? ep_relax : 0); par ^= 1; P8_STAMP(tq1);                                       \
+        const unsigned long long dq = tq1 - tq0; tb0 += kt == 0 ? dq : 0; tb1 += kt == 1 ? dq : 0; tb2 += kt == 2 ? dq : 0; tb3 += kt == 3 ? dq : 0; \
+        tb4 += (kt >= 4 && kt < 8) ? dq : 0; tb5 += kt >= 8 ? dq : 0; } } while (0)
+#else
 #define P8_LOOP(MASK) do { _Pragma("unroll 1") for (int kt = 0; kt < nk; ++kt) { ktile(par, std::integral_constant<int, MASK>{}, kt == 0 ? ep_relax : 0); par ^= 1; } } while (0)
+#endif
         const int optm = (EPI == 1 || EPI == 3) ? (bgrad ? 1 : 0) | (reluA ? 2 : 0) | (reluB ? 4 : 0) : 0;
         if (optm == 0) P8_LOOP(0);
         else if (optm == 1) P8_LOOP(1);
@@ -623,9 +640,12 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
             __builtin_amdgcn_s_barrier();
             continue;                                      // (next output tile)
         }
-        const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) && (!G16 || (reinterpret_cast<uintptr_t>(G16) & 7) == 0) &&
+        // (16-byte stores: fp32 at columns 4 g, bf16 at columns 8 g of a row)
+        const bool vec = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) &&
+                         (!G16 || (((ldc & 7) == 0) && (reinterpret_cast<uintptr_t>(G16) & 15) == 0)) &&
                          (!res || (((ldres & 3) == 0) && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
-                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!C16 || (reinterpret_cast<uintptr_t>(C16) & 7) == 0);
+                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
+                         (!C16 || (((ldc & 7) == 0) && (reinterpret_cast<uintptr_t>(C16) & 15) == 0));
         const bool whole = vec && m0 + C::BM <= Mm && n0 + C::BN <= Nn;               // block-uniform
         // one 16-row x 16-column block of the wave: lane -> row lr, columns 4 g .. 4 g + 3
         auto element = [&](float a, float bv, float rv) {                              // the element order of ring_epilogue
@@ -637,50 +657,95 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
         };
         ep_relax = 0;
         if (whole) {
-            // (what the next tile's first counted wait may leave in flight: exactly these stores; loads the compiler waits for itself)
-            const int n_st = (no32 ? 0 : 32) + ((EPI == 2 && C16) ? 32 : 0);
-            ep_relax = n_st >= 57 ? 57 : n_st == 32 ? 32 : 0;
-            // straight-line stores: no masks, no branches (32 x 16-byte stores per lane; the residual of block b + 1 is requested before
-            // block b is stored - loads and stores share one in-order counter)
+            // Store SHAPE decides how fast a CU gets its tile out (tools/store_probe: every CU writing 256 x 256 tiles, cycles per tile):
+            //   fp32, 16 rows x 64 bytes per instruction (a lane's four columns of one 16-column block)   33.9k   3.8 TB/s
+            //   fp32,  8 rows x 128 bytes                                                               23.0k   5.2 TB/s
+            //   bf16, 16 rows x 32 bytes (8 bytes per lane)                                              16.7k   4.1 TB/s
+            //   bf16, 16 rows x 64 bytes (16 bytes per lane)                                              9.1k   5.7 TB/s
+            // so the two 16-column blocks (j = 0, 1) of a row leave TOGETHER:
+            //   fp32: lanes lr >= 8 trade registers with lanes lr - 8 (DPP row_ror:8 under a bank mask) - instruction 0 carries rows 0..7 of the
+            //         16-row block with all 32 columns (j = 0 from the lanes lr < 8, j = 1 from the lanes lr >= 8), instruction 1 rows 8..15;
+            //   bf16: v_permlane32_swap + v_permlane16_swap of the packed pairs leave lane group q with columns 8 q .. 8 q + 7 of row lr.
+            // The residual (EPI 2) is added in place BEFORE the first store, in batches of eight loads: loads and stores share one in-order
+            // counter, and a load issued behind stores waits for them (24k cycles per tile with the loads between the stores, 12k without).
+            const bool has16 = (EPI == 2 && C16) || (EPI == 1 && G16);
+            const bool has32 = !(no32 || (EPI == 1 && G16));
+            const int n_st = (has32 ? 32 : 0) + (has16 ? 16 : 0);
+            ep_relax = n_st;
+            if constexpr (EPI == 2) {
+                if (bias || relu_out || gelu) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                            if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) acc[a][b][i][j][e] = element(acc[a][b][i][j][e], bv[e], 0.f);
+                        }
+                }
+                if (res) {
+                    // two batches of sixteen loads (the fragment registers are free here): two memory round trips per tile
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        f32x4 rv[2][4][2];
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int row = m0 + a * 128 + wr * 64 + i * 16 + lr, col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                                    rv[b][i][j] = *reinterpret_cast<const f32x4*>(res + (size_t)((uint32_t)(row * ldres + col)));
+                                }
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[a][b][i][j] += rv[b][i][j];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // (no store may move above the last residual load)
+            uint16_t* __restrict__ O16 = EPI == 1 ? G16 : C16;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int col = n0 + b * 128 + wc * 32 + j * 16 + 4 * g;
-                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if constexpr (EPI == 2) { if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col); }
-                        f32x4 rv[4];
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 x0 = acc[a][b][i][0], x1 = acc[a][b][i][1];
+                        const int rowb = m0 + a * 128 + wr * 64 + i * 16, colb = n0 + b * 128 + wc * 32;
+                        if (has32) {
+                            f32x4 s0, s1;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if constexpr (EPI == 2) {
-                                const int row = m0 + a * 128 + wr * 64 + i * 16 + lr;
-                                if (res) rv[i] = *reinterpret_cast<const f32x4*>(res + (size_t)((uint32_t)(row * ldres + col)));
+                            for (int e = 0; e < 4; ++e) {
+                                // lanes lr >= 8 (banks 2, 3 of every row of 16 lanes) take x1 of lane lr - 8; lanes lr < 8 take x0 of lane lr + 8
+                                // (inline asm: through __builtin_amdgcn_update_dpp on vector elements hipcc 7.2 delivered element 0 four times)
+                                float d0 = x0[e], d1 = x1[e];
+                                asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(d0) : "v"(x1[e]));
+                                asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0x3" : "+v"(d1) : "v"(x0[e]));
+                                s0[e] = d0; s1[e] = d1;
                             }
+                            const size_t o0 = (size_t)((uint32_t)((rowb + (lr & 7)) * ldc + colb + 16 * (lr >> 3) + 4 * g));
+                            *reinterpret_cast<f32x4*>(Cp + o0) = s0;
+                            *reinterpret_cast<f32x4*>(Cp + o0 + (size_t)((uint32_t)(8 * ldc))) = s1;
                         }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = m0 + a * 128 + wr * 64 + i * 16 + lr;
-                            const size_t oc = (size_t)((uint32_t)(row * ldc + col));
-                            f32x4 v = acc[a][b][i][j];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = element(v[e], bv[e], rv[i][e]);
-                            if (EPI == 1 && G16) {
-                                uint2 hh;
-                                hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
-                                hh.y = (uint32_t)m2f_bf16_bits(v[2]) | ((uint32_t)m2f_bf16_bits(v[3]) << 16);
-                                *reinterpret_cast<uint2*>(G16 + oc) = hh;
-                            } else if (!no32) *reinterpret_cast<f32x4*>(Cp + oc) = v;
-                            if constexpr (EPI == 2) {
-                                if (C16) {
-                                    uint2 hh;
-                                    hh.x = (uint32_t)m2f_bf16_bits(v[0]) | ((uint32_t)m2f_bf16_bits(v[1]) << 16);
-                                    hh.y = (uint32_t)m2f_bf16_bits(v[2]) | ((uint32_t)m2f_bf16_bits(v[3]) << 16);
-                                    *reinterpret_cast<uint2*>(C16 + oc) = hh;
-                                }
-                            }
+                        if (has16) {
+                            uint32_t a0 = (uint32_t)m2f_bf16_bits(x0[0]) | ((uint32_t)m2f_bf16_bits(x0[1]) << 16);
+                            uint32_t a1 = (uint32_t)m2f_bf16_bits(x0[2]) | ((uint32_t)m2f_bf16_bits(x0[3]) << 16);
+                            uint32_t b0 = (uint32_t)m2f_bf16_bits(x1[0]) | ((uint32_t)m2f_bf16_bits(x1[1]) << 16);
+                            uint32_t b1 = (uint32_t)m2f_bf16_bits(x1[2]) | ((uint32_t)m2f_bf16_bits(x1[3]) << 16);
+                            // rows of 16 lanes [A0 A1 A2 A3], [B0 B1 B2 B3] -> (32-swap) [A0 A1 B0 B1], [A2 A3 B2 B3] -> (16-swap) [A0 A2 B0 B2], [A1 A3 B1 B3]
+                            p8_swap2(a0, b0); p8_swap2(a1, b1);
+                            ring_u32x4 w = {a0, a1, b0, b1};                    // lane group q: columns 8 q .. 8 q + 3 | 8 q + 4 .. 8 q + 7 of row lr
+                            *reinterpret_cast<ring_u32x4*>(O16 + (size_t)((uint32_t)((rowb + lr) * ldc + colb + 8 * g))) = w;
                         }
                     }
         } else {
@@ -714,13 +779,15 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                         }
         }
 #ifdef P8_TIMING
-        P8_STAMP(ts1); tep += ts1 - ts0;
+        P8_STAMP(ts1); tep += ts1 - ts0; ++ntile;
 #endif
     }
 #ifdef P8_TIMING
     if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) {
         for (int p = 0; p < 4; ++p) for (int q = 0; q < 3; ++q) m2f_p8_dbg[wr * 16 + p * 3 + q] += tacc[p][q];
         m2f_p8_dbg[wr * 16 + 12] += tk; m2f_p8_dbg[wr * 16 + 13] += tep;
+        m2f_p8_dbg[32 + wr * 16 + 0] += tb0; m2f_p8_dbg[32 + wr * 16 + 1] += tb1; m2f_p8_dbg[32 + wr * 16 + 2] += tb2; m2f_p8_dbg[32 + wr * 16 + 3] += tb3;
+        m2f_p8_dbg[32 + wr * 16 + 4] += tb4; m2f_p8_dbg[32 + wr * 16 + 5] += tb5; m2f_p8_dbg[32 + wr * 16 + 6] += ntile;
     }
 #endif
     // the stream ran past the end of the list: its last (zero-filling) pieces must not outlive the workgroup's LDS allocation

@@ -22,15 +22,16 @@ fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 64)()
 a, b = PB.operands(rc, M, N, K, 3)
 c = torch.empty(M, N, device="cuda")
+res = torch.randn(M, N, device="cuda") if (len(sys.argv) > 5 and sys.argv[5] == "res" and not rc) else None      # (k-contiguous form: + residual)
 for _ in range(3):
-    PB.run(rc, M, N, K, a.view(torch.int16), b.view(torch.int16), c)
+    PB.run(rc, M, N, K, a.view(torch.int16), b.view(torch.int16), c, res=res)
 torch.cuda.synchronize()
 assert fn(buf, 1) == 0
-PB.run(rc, M, N, K, a.view(torch.int16), b.view(torch.int16), c)
+PB.run(rc, M, N, K, a.view(torch.int16), b.view(torch.int16), c, res=res)
 torch.cuda.synchronize()
 assert fn(buf, 0) == 0
 v = list(buf)
-print(f"p8 {'RC' if rc else 'KC'} {M}x{N}x{K}: workgroup 0")
+print(f"p8 {'RC' if rc else 'KC'} {M}x{N}x{K}{' + residual' if res is not None else ''}: workgroup 0")
 for h, name in ((0, "wave 0 (upper half)"), (1, "wave 4 (lower half)")):
     o = h * 16
     kt = max(v[o + 12], 1)
@@ -39,3 +40,8 @@ for h, name in ((0, "wave 0 (upper half)"), (1, "wave 4 (lower half)")):
     for p in range(4):
         A, B_, C_ = v[o + 3 * p] / kt, v[o + 3 * p + 1] / kt, v[o + 3 * p + 2] / kt
         print(f"    phase {p + 1}: reads+stage+barrier+wait {A:7.0f} | 16 MFMAs {B_:6.0f} | closing barrier {C_:6.0f} | sum {A + B_ + C_:7.0f}")
+    nt = max(v[32 + o + 6], 1)
+    nk_tile = kt // nt
+    b = [v[32 + o + i] / nt for i in range(6)]
+    print(f"    by position inside an output tile ({nt} tiles of {nk_tile} k-tiles; stamps included): k-tile 0 {b[0]:.0f}, 1 {b[1]:.0f}, 2 {b[2]:.0f}, 3 {b[3]:.0f}, "
+          f"4-7 {b[4] / max(1, min(4, nk_tile - 4)):.0f} each, 8+ {b[5] / max(1, nk_tile - 8):.0f} each; epilogue {v[o + 13] / nt:.0f} per tile")

@@ -223,6 +223,17 @@ int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq,
 int m2f_attention_long_fwd_bf16(int B, int S, int H, int hd, const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v,
                                 int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, m2f_stream_t stream);
 
+/* ... with a third output (nullable like the others; at least one must be given): out8 = OCP e4m3 bytes of value * out8_scale,
+ * saturating at +-448 - the operand the fp8 output projection stages (no fp32 copy, no quantise pass); needs hd and ldo in multiples of 16. */
+int m2f_attention_long_fwd_bf16_out8(int B, int S, int H, int hd, const uint16_t* q, int ldq, const uint16_t* k, int ldk,
+                                     const uint16_t* v, int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, uint8_t* out8,
+                                     float out8_scale, int ldo, m2f_stream_t stream);
+
+/* m2f_layernorm_fwd that ALSO writes its result as e4m3(value * out8_scale), saturating, into out8 [T, d] (d % 4 == 0): the fp8 text
+ * encoder's LayerNorm outputs are GEMM operands (round 4: replaces a quantise pass over the fp32 result). */
+int m2f_layernorm_fwd_out8(int T, int d, const float* x, const float* gamma, const float* beta, const float* res, float* out,
+                           float* stats, float eps, uint8_t* out8, float out8_scale, m2f_stream_t stream);
+
 /* Results of the following m2f_gemm calls of this thread that have a bf16 shadow (m2f_set_shadow_map) have NO fp32 reader: kernels
  * that know how (the chip-filling bf16 forms) write the shadow only and leave the fp32 buffer untouched; edge tiles and the other
  * forms still write both.  0 switches it off.  (The plans decide this per buffer from their launch lists: m2f_plan_skipped_copies.) */

@@ -25,7 +25,8 @@ template <int CT>
 __global__ __launch_bounds__(NTHR) void m2f_attn_long_bf16_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                  const uint16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                                  const uint8_t* __restrict__ key_pad, uint16_t* __restrict__ out16,
-                                                                 float* __restrict__ out32, int ldo, int S, int H, int hd) {
+                                                                 float* __restrict__ out32, uint8_t* __restrict__ out8, float out8_scale, int ldo, int S,
+                                                                 int H, int hd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int W = 16 * CT, LD = 2 * W + 16, CH = W / 8;      // LDS row bytes; 16-byte chunks per row
     char* Qs = smem;
@@ -134,39 +135,68 @@ __global__ __launch_bounds__(NTHR) void m2f_attn_long_bf16_kernel(const uint16_t
 #pragma unroll
     for (int r = 0; r < 4; ++r) inv4[r] = __shfl(inv, 4 * lg + r, 64);
     // the wave's 16 x W result through ITS OWN rows of the Q slab (its Q fragments live in registers since the first block), so that the
-    // rows leave as 16-byte stores
+    // rows leave as 16-byte stores: as bf16 (out16), and / or as OCP e4m3 bytes of value * out8_scale, saturating (out8: the operand the
+    // fp8 output projection stages - no fp32 copy, no quantise pass)
+    if (out16 || out32) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float val = o[ct][r] * inv4[r];
-            *reinterpret_cast<uint16_t*>(Qs + (16 * wv + 4 * lg + r) * LD + 2 * (16 * ct + l15)) = m2f_bf16_bits(val);
-            if (out32) {
-                const int io = q0 + 16 * wv + 4 * lg + r, c = 16 * ct + l15;
-                if (io < S && c < hd) out32[(tok0 + io) * ldo + h * hd + c] = val;
+            for (int r = 0; r < 4; ++r) {
+                const float val = o[ct][r] * inv4[r];
+                if (out16) *reinterpret_cast<uint16_t*>(Qs + (16 * wv + 4 * lg + r) * LD + 2 * (16 * ct + l15)) = m2f_bf16_bits(val);
+                if (out32) {
+                    const int io = q0 + 16 * wv + 4 * lg + r, c = 16 * ct + l15;
+                    if (io < S && c < hd) out32[(tok0 + io) * ldo + h * hd + c] = val;
+                }
+            }
+        __syncthreads();
+        if (out16) {
+#pragma unroll
+            for (int e0 = 0; e0 < 16 * CH; e0 += 64) {
+                const int e = e0 + lane;
+                const int r = e / CH, c = e - r * CH;
+                if (e < 16 * CH && 16 * wv + r < nq && 8 * c < hd)
+                    *reinterpret_cast<u32x4*>(out16 + (tok0 + q0 + 16 * wv + r) * ldo + h * hd + 8 * c) =
+                        *reinterpret_cast<const u32x4*>(Qs + (16 * wv + r) * LD + 16 * c);
             }
         }
-    __syncthreads();
+        __syncthreads();
+    }
+    if (out8) {
 #pragma unroll
-    for (int e0 = 0; e0 < 16 * CH; e0 += 64) {
-        const int e = e0 + lane;
-        const int r = e / CH, c = e - r * CH;
-        if (e < 16 * CH && 16 * wv + r < nq && 8 * c < hd)
-            *reinterpret_cast<u32x4*>(out16 + (tok0 + q0 + 16 * wv + r) * ldo + h * hd + 8 * c) =
-                *reinterpret_cast<const u32x4*>(Qs + (16 * wv + r) * LD + 16 * c);
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float val = fminf(fmaxf(o[ct][r] * inv4[r] * out8_scale, -448.f), 448.f);
+                const int w = __builtin_amdgcn_cvt_pk_fp8_f32(val, val, 0, false);
+                *reinterpret_cast<uint8_t*>(Qs + (16 * wv + 4 * lg + r) * LD + (16 * ct + l15)) = (uint8_t)(w & 0xff);
+            }
+        __syncthreads();
+        constexpr int CH8 = W / 16;                              // 16-byte chunks of a row of W bytes (hd % 16 == 0 on this path)
+#pragma unroll
+        for (int e0 = 0; e0 < 16 * CH8; e0 += 64) {
+            const int e = e0 + lane;
+            const int r = e / CH8, c = e - r * CH8;
+            if (e < 16 * CH8 && 16 * wv + r < nq && 16 * c < hd)
+                *reinterpret_cast<u32x4*>(out8 + (tok0 + q0 + 16 * wv + r) * ldo + h * hd + 16 * c) =
+                    *reinterpret_cast<const u32x4*>(Qs + (16 * wv + r) * LD + 16 * c);
+        }
     }
 }
 
 }  // namespace
 
-// q / k / v: bf16 [B * S, ...] with leading dimensions ldq / ldk / ldv (elements), head h in columns h hd .. h hd + hd - 1; out16 (bf16) is
-// always written, out32 (fp32, same indexing) when not null.  hd, the leading dimensions and the base addresses in units of 8 elements.
+// q / k / v: bf16 [B * S, ...] with leading dimensions ldq / ldk / ldv (elements), head h in columns h hd .. h hd + hd - 1; outputs, each
+// nullable, at least one, all [B * S, ldo]: out16 (bf16), out32 (fp32), out8 (e4m3 of value * out8_scale, saturating; needs hd and ldo in
+// units of 16).  hd, the leading dimensions and the base addresses in units of 8 elements.
 hipError_t m2f_launch_attn_long_fwd_bf16(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
-                                         const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, int B, int S, int H, int hd,
-                                         hipStream_t stream) {
-    if (B < 1 || S < 1 || H < 1 || hd < 8 || hd > 128 || (hd & 7) || !q || !k || !v || !out16) return hipErrorInvalidValue;
+                                         const uint8_t* key_pad, uint16_t* out16, float* out32, uint8_t* out8, float out8_scale, int ldo,
+                                         int B, int S, int H, int hd, hipStream_t stream) {
+    if (B < 1 || S < 1 || H < 1 || hd < 8 || hd > 128 || (hd & 7) || !q || !k || !v || !(out16 || out32 || out8)) return hipErrorInvalidValue;
     if ((ldq | ldk | ldv | ldo) & 7) return hipErrorInvalidValue;
-    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out16)) & 15)
+    if (out8 && ((hd & 15) || (ldo & 15) || (reinterpret_cast<uintptr_t>(out8) & 15))) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out16) |
+         reinterpret_cast<uintptr_t>(out32)) & 15)
         return hipErrorInvalidValue;
     if ((S + 63) / 64 > 65535 || (long long)B * H > 0x7fffffffLL) return hipErrorInvalidValue;
     const int CT = (hd + 15) / 16;
@@ -175,7 +205,7 @@ hipError_t m2f_launch_attn_long_fwd_bf16(const uint16_t* q, int ldq, const uint1
 #define M2F_ALB_CASE(N)                                                                                                          \
     case N:                                                                                                                      \
         hipLaunchKernelGGL(m2f_attn_long_bf16_kernel<N>, grid, dim3(NTHR), lds, stream, q, k, v, ldq, ldk, ldv, key_pad, out16,  \
-                           out32, ldo, S, H, hd);                                                                                \
+                           out32, out8, out8_scale, ldo, S, H, hd);                                                               \
         break;
     switch (CT) {
         M2F_ALB_CASE(1) M2F_ALB_CASE(2) M2F_ALB_CASE(3) M2F_ALB_CASE(4) M2F_ALB_CASE(5) M2F_ALB_CASE(6) M2F_ALB_CASE(7) M2F_ALB_CASE(8)

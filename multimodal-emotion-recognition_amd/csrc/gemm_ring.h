@@ -202,7 +202,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                         v[e] = element(ftag, a[p][e], bv[j][e], (F & 4) ? t.r[p][e] : 0.f, (F & 2) ? t.g[p][e] : 1.f, (F & 8) ? t.c[p][e] : 0.f, row, col + e);
                     if constexpr (EPI == 4) {                        // fp8 launches: e4m3(result * c8_scale) instead of fp32 C (block-uniform), no shadow
                         if (c8) *reinterpret_cast<uint32_t*>(c8 + (size_t)oc) = m2f_fp8x4_bits(v[0] * c8s, v[1] * c8s, v[2] * c8s, v[3] * c8s);
-                        else *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;
+                        else if constexpr (!(F & 32)) *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;      // (F & 32: bf16 shadow only, GF_NO_F32)
                     } else if constexpr (!(F & 32)) *reinterpret_cast<f32x4*>(C + (size_t)oc) = v;      // F & 32: C has no fp32 reader (GF_NO_F32)
                     if (C16) {
                         uint2 hh;
@@ -225,7 +225,8 @@ __device__ __forceinline__ void ring_epilogue(const GemmBatch& gb, const RingEpi
                 default: blocks(std::integral_constant<int, 20>{}); break;
             }
         } else if constexpr (EPI == 4) {                            // fp8 launches: {-, residual} x {-, GELU}, always de-quantising
-            switch (fmask & ~32) {
+            if (fmask == 32) blocks(std::integral_constant<int, 32>{});       // bias only, bf16 shadow only (the packed Q / K / V projection)
+            else switch (fmask & ~32) {
                 case 0: blocks(std::integral_constant<int, 0>{}); break;
                 case 4: blocks(std::integral_constant<int, 4>{}); break;
                 case 16: blocks(std::integral_constant<int, 16>{}); break;

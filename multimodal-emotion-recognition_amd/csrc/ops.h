@@ -197,8 +197,8 @@ hipError_t m2f_launch_attn_fwd(AttnBatch& ab, hipStream_t stream);
 // Long-sequence forward (S unbounded, hd <= 128): token-level self-attention of the in-loop text encoder (inference).
 // q/k/v rows are token-major (token t = b*S + i), head h in columns [h*hd, (h+1)*hd); key_pad [B, S] (1 = padded, nullable).
 hipError_t m2f_launch_attn_long_fwd_bf16(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
-                                         const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, int B, int S, int H, int hd,
-                                         hipStream_t stream);
+                                         const uint8_t* key_pad, uint16_t* out16, float* out32, uint8_t* out8, float out8_scale, int ldo,
+                                         int B, int S, int H, int hd, hipStream_t stream);
 hipError_t m2f_launch_attn_long_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                     const uint8_t* key_pad, float* out, int ldo, int B, int S, int H, int hd, ShadowMap sh,
                                     hipStream_t stream);
@@ -234,6 +234,8 @@ struct LnBatch {
     float eps;
     const uint32_t* rng; uint32_t drop_thresh; float drop_scale;
     ShadowMap sh;                      // out (fwd) / dx, dx_masked (bwd) also written as bf16
+    uint8_t* out8; float out8_scale;   // forward, problem 0 only (nullable): out ALSO as OCP e4m3 bytes of value * out8_scale, saturating, row stride d
+                                       // (the operand the text encoder's fp8 GEMMs stage: no quantise pass; d % 4 == 0)
 };
 #define M2F_LN_ROWS_PER_BLOCK 4
 hipError_t m2f_launch_ln_fwd(LnBatch& lb, hipStream_t stream);

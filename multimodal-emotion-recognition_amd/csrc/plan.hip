@@ -2115,7 +2115,7 @@ int m2f_gemm_fp8(int M, int N, int K, const uint8_t* a8, int lda, const uint8_t*
     p.M = M; p.N = N; p.c = c; p.ldc = ldc; p.bias = bias; p.res = res; p.ldres = ldres;
     p.gate_scale = 1.f; p.acc_scale = acc_scale; p.c8 = c8; p.c8_scale = c8_scale;
     if (!c && !c8) return fail("m2f_gemm_fp8: no output buffer");
-    p.flags = (activation == 1 ? GF_RELU_OUT : 0) | (activation == 2 ? GF_GELU_OUT : 0);
+    p.flags = (activation == 1 ? GF_RELU_OUT : 0) | (activation == 2 ? GF_GELU_OUT : 0) | (g_shadow_only && c && !c8 ? GF_NO_F32 : 0);
     gb.pr[0] = p; gb.count = 1; gb.sh = g_sh;
     M2F_HIP(m2f_launch_gemm_fp8(gb, static_cast<hipStream_t>(stream)));
     return 0;
@@ -2173,6 +2173,18 @@ int m2f_layernorm_fwd(int T, int d, const float* x, const float* gamma, const fl
     return 0;
 }
 
+int m2f_layernorm_fwd_out8(int T, int d, const float* x, const float* gamma, const float* beta, const float* res, float* out,
+                           float* stats, float eps, uint8_t* out8, float out8_scale, m2f_stream_t stream) {
+    if (!out8 || (d & 3) || (reinterpret_cast<uintptr_t>(out8) & 3)) return fail("m2f_layernorm_fwd_out8: e4m3 output needs d % 4 == 0 and a 4-byte aligned buffer");
+    LnBatch lb;
+    memset(&lb, 0, sizeof(lb));
+    LnProblem& p = lb.pr[0];
+    p.x = x; p.gamma = gamma; p.beta = beta; p.res = res; p.out = out; p.stats = stats; p.d = d;
+    lb.count = 1; lb.T = T; lb.eps = eps; lb.drop_scale = 1.f; lb.sh = g_sh; lb.out8 = out8; lb.out8_scale = out8_scale;
+    M2F_HIP(m2f_launch_ln_fwd(lb, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int m2f_embed_layernorm(int T, int d, const int64_t* input_ids, const int64_t* position_ids, const float* word_emb,
                         const float* pos_emb, const float* type_emb_row0, const float* gamma, const float* beta, float eps,
                         float* out, int ld_out, m2f_stream_t stream) {
@@ -2189,10 +2201,17 @@ int m2f_attention_long_fwd(int B, int S, int H, int hd, const float* q, int ldq,
 
 int m2f_attention_long_fwd_bf16(int B, int S, int H, int hd, const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v,
                                 int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, int ldo, m2f_stream_t stream) {
-    if (!q || !k || !v || !out16) return fail("m2f_attention_long_fwd_bf16: NULL operand");
+    return m2f_attention_long_fwd_bf16_out8(B, S, H, hd, q, ldq, k, ldk, v, ldv, key_pad, out16, out32, nullptr, 1.f, ldo, stream);
+}
+
+int m2f_attention_long_fwd_bf16_out8(int B, int S, int H, int hd, const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v,
+                                     int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, uint8_t* out8, float out8_scale, int ldo,
+                                     m2f_stream_t stream) {
+    if (!q || !k || !v || !(out16 || out32 || out8)) return fail("m2f_attention_long_fwd_bf16: NULL operand / no output");
     if (hd < 8 || hd > 128 || (hd & 7) || ((ldq | ldk | ldv | ldo) & 7))
         return fail("m2f_attention_long_fwd_bf16: head dim and leading dimensions must be multiples of 8, head dim <= 128");
-    M2F_HIP(m2f_launch_attn_long_fwd_bf16(q, ldq, k, ldk, v, ldv, key_pad, out16, out32, ldo, B, S, H, hd, static_cast<hipStream_t>(stream)));
+    if (out8 && ((hd & 15) || (ldo & 15))) return fail("m2f_attention_long_fwd_bf16: the e4m3 output needs head dim and ldo in multiples of 16");
+    M2F_HIP(m2f_launch_attn_long_fwd_bf16(q, ldq, k, ldk, v, ldv, key_pad, out16, out32, out8, out8_scale, ldo, B, S, H, hd, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

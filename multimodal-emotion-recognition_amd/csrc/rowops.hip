@@ -132,6 +132,15 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
             }
         row_store(x, P.out + (size_t)row * ld, d, vec, lane);
         if (out16) row_store_bf16(x, out16 + (size_t)row * ld, d, lane);
+        if (lb.out8 && pi == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * (lane + 64 * j);
+                if (c + 3 < d)
+                    *reinterpret_cast<uint32_t*>(lb.out8 + (size_t)row * d + c) =
+                        m2f_fp8x4_bits(x.v[j][0] * lb.out8_scale, x.v[j][1] * lb.out8_scale, x.v[j][2] * lb.out8_scale, x.v[j][3] * lb.out8_scale);
+            }
+        }
         if (lane == 0) { P.stats[2 * row] = mean; P.stats[2 * row + 1] = rstd; }
     }
 }

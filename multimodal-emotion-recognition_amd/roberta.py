@@ -133,8 +133,9 @@ class RobertaEncoder(torch.nn.Module):
         w = self._ws.get(key)
         if w is None:
             T, d, Fi = B * S, self.d, self.inter
-            # ("t" LAST: the bf16 mode leaves it outside the shadow map - its only reader is the LayerNorm kernel, which reads fp32)
-            sizes = {"x": T * d, "qkv": T * 3 * d, "ctx": T * d, "y1": T * d, "h": T * Fi, "t": T * d}
+            # ("t" LAST: the bf16 mode leaves it outside the shadow map - its only reader is the LayerNorm kernel, which reads fp32;
+            #  "qkv" FIRST: the fp8 mode maps nothing else - the packed projection is the one activation it keeps as bf16)
+            sizes = {"qkv": T * 3 * d, "x": T * d, "ctx": T * d, "y1": T * d, "h": T * Fi, "t": T * d}
             total = sum((n + 63) // 64 * 64 for n in sizes.values())
             ws = torch.zeros(total, dtype=torch.float32, device=dev)
             ws16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)
@@ -144,7 +145,7 @@ class RobertaEncoder(torch.nn.Module):
                 views[name] = ws[off: off + n].view(T, cols)
                 views16[name] = ws16[off: off + n].view(T, cols)
                 off += (n + 63) // 64 * 64
-            w = {"ws": ws, "ws16": ws16, "v": views, "v16": views16, "mapped": total - (T * d + 63) // 64 * 64, "stats": torch.empty(T, 2, dtype=torch.float32, device=dev)}
+            w = {"ws": ws, "ws16": ws16, "v": views, "v16": views16, "mapped": total - (T * d + 63) // 64 * 64, "mapped8": (T * 3 * d + 63) // 64 * 64, "stats": torch.empty(T, 2, dtype=torch.float32, device=dev)}
             if self.fp8:
                 w["q8"] = {n: torch.empty(T, c, dtype=torch.float8_e4m3fn, device=dev) for n, c in (("x", d), ("ctx", d), ("y1", d), ("h", Fi))}
             self._ws[key] = w
@@ -171,8 +172,14 @@ class RobertaEncoder(torch.nn.Module):
         # bf16 mode (round 4): the packed projection, the attention context and the FFN hidden activation exist ONLY as bf16 (their one
         # reader is the next GEMM / the attention kernel, which stage bf16 anyway); the residual stream and the LayerNorm inputs stay fp32
         lean = bf16 and d % 8 == 0 and hd % 8 == 0 and not _FAT_BF16
-        check(lib().m2f_set_shadow_map(ptr(w["ws"]) if bf16 else None, ptr(w["ws16"]) if bf16 else None,
-                                       (w["mapped"] if lean else w["ws"].numel()) if bf16 else 0), "m2f_set_shadow_map")
+        # fp8 mode (round 4): the packed projection only as bf16 (the attention kernel's operand), the attention context and the LayerNorm
+        # results as e4m3 straight from the kernels that produce them (they are GEMM operands): no fp32 copies of those, no quantise passes
+        lean8 = self.fp8 and d % 16 == 0 and hd % 16 == 0 and not _FAT_BF16
+        if lean8:
+            check(lib().m2f_set_shadow_map(ptr(w["ws"]), ptr(w["ws16"]), w["mapped8"]), "m2f_set_shadow_map")
+        else:
+            check(lib().m2f_set_shadow_map(ptr(w["ws"]) if bf16 else None, ptr(w["ws16"]) if bf16 else None,
+                                           (w["mapped"] if lean else w["ws"].numel()) if bf16 else 0), "m2f_set_shadow_map")
         try:
             ids = input_ids.reshape(-1).to(torch.int64).contiguous()
             keep = input_ids.ne(self.pad_id).to(torch.int64)
@@ -189,10 +196,16 @@ class RobertaEncoder(torch.nn.Module):
                 if self.fp8:
                     sa = ACT_SCALE[a_name]
                     q8 = w["q8"][a_name]
-                    if a_name != "h":                                        # h arrives quantised from the FFN1 epilogue
+                    if a_name != "h" and not (lean8 and a_name in fresh8):   # h arrives quantised from the FFN1 epilogue
                         F.quantize_fp8(v[a_name], sa, out=q8)
-                    F.gemm_fp8(q8, L[wkey + "8"], 1.0 / (sa * L[wkey + "8s"]), bias=bias, res=res, activation=act, out=out,
-                               out8=w["q8"][out8] if out8 else None, out8_scale=ACT_SCALE[out8] if out8 else 1.0)
+                    if lean8 and out16_only and not out8:
+                        check(lib().m2f_set_shadow_only(1), "m2f_set_shadow_only")
+                    try:
+                        F.gemm_fp8(q8, L[wkey + "8"], 1.0 / (sa * L[wkey + "8s"]), bias=bias, res=res, activation=act, out=out,
+                                   out8=w["q8"][out8] if out8 else None, out8_scale=ACT_SCALE[out8] if out8 else 1.0)
+                    finally:
+                        if lean8 and out16_only and not out8:
+                            check(lib().m2f_set_shadow_only(0), "m2f_set_shadow_only")
                 else:
                     if lean and out16_only:
                         check(lib().m2f_set_shadow_only(1), "m2f_set_shadow_only")
@@ -202,9 +215,25 @@ class RobertaEncoder(torch.nn.Module):
                     finally:
                         if lean and out16_only:
                             check(lib().m2f_set_shadow_only(0), "m2f_set_shadow_only")
+            fresh8 = set()                   # fp8 mode: activations whose e4m3 copy the producing kernel wrote itself
+
+            def layernorm(src, g, b, dst):
+                if lean8:
+                    check(lib().m2f_layernorm_fwd_out8(T, d, ptr(v[src]), ptr(g), ptr(b), None, ptr(v[dst]), ptr(w["stats"]), self.eps,
+                                                       ptr(w["q8"][dst]), ACT_SCALE[dst], stream_ptr()), "m2f_layernorm_fwd_out8")
+                    fresh8.add(dst)
+                else:
+                    check(lib().m2f_layernorm_fwd(T, d, ptr(v[src]), ptr(g), ptr(b), None, ptr(v[dst]), ptr(w["stats"]), self.eps,
+                                                  stream_ptr()), "m2f_layernorm_fwd")
             for L in self._packed:
                 linear("x", "wqkv", L, v["qkv"], L["bqkv"], out16_only=True)
-                if lean:
+                if lean8:
+                    q16 = v16["qkv"]
+                    check(lib().m2f_attention_long_fwd_bf16_out8(B, S, H, hd, ptr(q16), 3 * d, q16.data_ptr() + 2 * d, 3 * d,
+                                                                 q16.data_ptr() + 4 * d, 3 * d, ptr(key_pad), None, None, ptr(w["q8"]["ctx"]),
+                                                                 ACT_SCALE["ctx"], d, stream_ptr()), "m2f_attention_long_fwd_bf16_out8")
+                    fresh8.add("ctx")
+                elif lean:
                     q16 = v16["qkv"]
                     check(lib().m2f_attention_long_fwd_bf16(B, S, H, hd, ptr(q16), 3 * d, q16.data_ptr() + 2 * d, 3 * d,
                                                             q16.data_ptr() + 4 * d, 3 * d, ptr(key_pad), ptr(v16["ctx"]), None, d,
@@ -215,12 +244,10 @@ class RobertaEncoder(torch.nn.Module):
                                                        qkv.data_ptr() + 8 * d, 3 * d, ptr(key_pad), ptr(v["ctx"]), d, stream_ptr()),
                           "m2f_attention_long_fwd")
                 linear("ctx", "wo", L, v["t"], L["bo"], res=v["x"])
-                check(lib().m2f_layernorm_fwd(T, d, ptr(v["t"]), ptr(L["g1"]), ptr(L["b1"]), None, ptr(v["y1"]), ptr(w["stats"]),
-                                              self.eps, stream_ptr()), "m2f_layernorm_fwd")
+                layernorm("t", L["g1"], L["b1"], "y1")
                 linear("y1", "wi", L, v["h"], L["bi"], act=2, out8="h" if self.fp8 else None, out16_only=True)
                 linear("h", "wo2", L, v["t"], L["bo2"], res=v["y1"])
-                check(lib().m2f_layernorm_fwd(T, d, ptr(v["t"]), ptr(L["g2"]), ptr(L["b2"]), None, ptr(v["x"]), ptr(w["stats"]),
-                                              self.eps, stream_ptr()), "m2f_layernorm_fwd")
+                layernorm("t", L["g2"], L["b2"], "x")
             out = v["x"].view(B, S, d).clone()
         finally:
             check(lib().m2f_set_shadow_map(None, None, 0), "m2f_set_shadow_map")

@@ -118,6 +118,10 @@ SIGNATURES = {
                                     c_float, c_void_p, c_int, c_void_p]),
     "m2f_attention_long_fwd_bf16": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "m2f_attention_long_fwd_bf16_out8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    "m2f_layernorm_fwd_out8": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float,
+                                       c_void_p]),
     "m2f_set_shadow_only": (c_int, [c_int]),
     "m2f_attention_long_fwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p, c_int, c_void_p]),

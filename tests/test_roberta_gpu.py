@@ -199,3 +199,39 @@ def test_bf16_mode_lean_and_fat_data_flows_agree():
     print(f"bf16 text encoder vs oracle: lean max {e_lean.max():.3e} mean {e_lean.mean():.3e}; fat max {e_fat.max():.3e} mean {e_fat.mean():.3e}")
     assert e_lean.max().item() < 6e-2 and e_lean.mean().item() < 1e-2
     assert e_lean.mean().item() < 1.5 * e_fat.mean().item() + 1e-4
+
+
+def test_e4m3_outputs_of_attention_and_layernorm_equal_a_quantise_pass_over_their_fp32_results():
+    """fp8 mode (round 4): the attention kernel and the LayerNorm kernel write the e4m3 operand of the next GEMM themselves.  Same bytes
+    as m2f_quantize_fp8 over the fp32 result of the same launch (same scale, same saturation)."""
+    from mer_amd import runtime
+    from mer_amd import functional as F
+    B, S, H, hd = 3, 70, 4, 32
+    d = H * hd
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * S, 3 * d, generator=g) * 2.0).cuda().to(torch.bfloat16)
+    key_pad = torch.zeros(B, S, dtype=torch.uint8)
+    key_pad[1, 50:] = 1
+    key_pad = key_pad.cuda()
+    out32 = torch.full((B * S, d), float("nan"), device="cuda")
+    out8 = torch.zeros(B * S, d, dtype=torch.uint8, device="cuda")
+    runtime.check(runtime.lib().m2f_attention_long_fwd_bf16_out8(B, S, H, hd, qkv.data_ptr(), 3 * d, qkv.data_ptr() + 2 * d, 3 * d,
+                                                                 qkv.data_ptr() + 4 * d, 3 * d, key_pad.data_ptr(), None, out32.data_ptr(),
+                                                                 out8.data_ptr(), 16.0, d, runtime.stream_ptr()), "m2f_attention_long_fwd_bf16_out8")
+    want = F.quantize_fp8(out32, 16.0)
+    torch.cuda.synchronize()
+    assert torch.equal(out8, want.view(torch.uint8))
+    assert out8.ne(0).float().mean().item() > 0.9                      # (not an all-zero comparison)
+    T, dl = 37, 768
+    x = (torch.randn(T, dl, generator=g) * 3.0 + 0.5).cuda()
+    gam, bet = (torch.rand(dl, generator=g) + 0.5).cuda(), torch.randn(dl, generator=g).cuda()
+    y = torch.empty(T, dl, device="cuda")
+    st = torch.empty(T, 2, device="cuda")
+    y8 = torch.zeros(T, dl, dtype=torch.uint8, device="cuda")
+    runtime.check(runtime.lib().m2f_layernorm_fwd_out8(T, dl, x.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, y.data_ptr(), st.data_ptr(), 1e-5,
+                                                       y8.data_ptr(), 16.0, runtime.stream_ptr()), "m2f_layernorm_fwd_out8")
+    ref = torch.nn.functional.layer_norm(x, (dl,), gam, bet, 1e-5)
+    torch.cuda.synchronize()
+    assert (y - ref).abs().max().item() < 1e-4
+    assert torch.equal(y8, F.quantize_fp8(y, 16.0).view(torch.uint8))
+    assert (y.abs() * 16.0 > 448).any()                               # (the saturating branch is exercised)

@@ -225,6 +225,7 @@ def test_e4m3_outputs_of_attention_and_layernorm_equal_a_quantise_pass_over_thei
     T, dl = 37, 768
     x = (torch.randn(T, dl, generator=g) * 3.0 + 0.5).cuda()
     gam, bet = (torch.rand(dl, generator=g) + 0.5).cuda(), torch.randn(dl, generator=g).cuda()
+    gam[:8] *= 40.0                                                     # (some results beyond +-448 / 16: the saturating branch)
     y = torch.empty(T, dl, device="cuda")
     st = torch.empty(T, 2, device="cuda")
     y8 = torch.zeros(T, dl, dtype=torch.uint8, device="cuda")
@@ -232,6 +233,6 @@ def test_e4m3_outputs_of_attention_and_layernorm_equal_a_quantise_pass_over_thei
                                                        y8.data_ptr(), 16.0, runtime.stream_ptr()), "m2f_layernorm_fwd_out8")
     ref = torch.nn.functional.layer_norm(x, (dl,), gam, bet, 1e-5)
     torch.cuda.synchronize()
-    assert (y - ref).abs().max().item() < 1e-4
+    assert (y - ref).abs().max().item() < 1e-3
     assert torch.equal(y8, F.quantize_fp8(y, 16.0).view(torch.uint8))
     assert (y.abs() * 16.0 > 448).any()                               # (the saturating branch is exercised)

@@ -29,12 +29,16 @@ else
     python3 tools/bench_text_encoder.py --model $m > $O/f4_text_encoder_${m}_bf16.json 2>> $O/err.txt
     python3 tools/bench_text_encoder.py --model $m --dtype fp8 > $O/f4_text_encoder_${m}_fp8.json 2>> $O/err.txt
   done
-  M2F_P8=0 python3 tools/bench_text_encoder.py --model large > $O/f4_text_encoder_large_bf16_no_p8.json 2>> $O/err.txt
+  M2F_ROBERTA_FAT=1 python3 tools/bench_text_encoder.py --model large > $O/f4_text_encoder_large_bf16_round3_dataflow.json 2>> $O/err.txt
+  M2F_ROBERTA_FAT=1 python3 tools/bench_text_encoder.py --model large --dtype fp8 > $O/f4_text_encoder_large_fp8_round3_dataflow.json 2>> $O/err.txt
+  for m in bf16 fp8; do tools/kstats_cmd.sh ${tag}_f4_$m tools/bench_text_encoder.py --model large --dtype $m > $O/f4_text_encoder_large_kernel_stats_$m.txt 2>&1; done
   python3 tools/bench_text_encoder.py --model large --utterances 1024 --with-fusion-step > $O/f4_c5_dataflow_large_bf16.json 2>> $O/err.txt
   python3 tools/p8_bench.py bench 20 2>&1 | grep -v amdgpu.ids > $O/p8_kernel_bench.txt
+  tools/store_probe/store_probe 4096 > $O/store_shape_probe.txt 2>&1
   python3 tools/chain_floor.py c3 2>&1 | grep -v amdgpu.ids > $O/chain_gemm_floor_c3.txt
   if [ -f $D/libm2fnet_hip_p8timing.so ]; then
-    for S in "1 8192 8192 1024" "0 32768 4096 1024" "1 4096 4096 4096"; do M2F_LIB=$D/libm2fnet_hip_p8timing.so python3 tools/p8_timing.py $S 2>&1 | grep -v amdgpu.ids >> $O/p8_phase_totals.txt; done
+    rm -f $O/p8_phase_totals.txt
+    for S in "1 8192 8192 1024" "0 32768 4096 1024" "0 32768 1024 1024 res" "0 32768 1024 4096 res" "1 4096 4096 4096"; do M2F_LIB=$D/libm2fnet_hip_p8timing.so python3 tools/p8_timing.py $S 2>&1 | grep -v amdgpu.ids >> $O/p8_phase_totals.txt; done
   fi
   echo done > $O/DONE2
 fi

@@ -1513,6 +1513,15 @@ hipError_t m2f_launch_gemm_fp8(GemmBatch& gb, hipStream_t stream) {
     // the staging code moves 16-byte chunks of a row whatever they hold: hand it the rows in byte pairs
     p.a.k[0] >>= 1; p.b.k[0] >>= 1; p.a.ldq[0] >>= 1; p.b.ldq[0] >>= 1;
     const bool gelu = p.flags & GF_GELU_OUT;
+    {   // round 4: 256x256 tiles on the eight-phase schedule (gemm_p8.h, EPI 4) from one chip-filling round on, when its tiles fill whole rounds
+        // (M2F_P8=0 / M2F_P8_MIN as for the bf16 launches; k a multiple of 128)
+        static const int p8_on = getenv("M2F_P8") ? atoi(getenv("M2F_P8")) : 1;
+        static const int p8_min = getenv("M2F_P8_MIN") ? atoi(getenv("M2F_P8_MIN")) : 256;
+        const int t256 = m2f_cdiv(p.M, 256) * m2f_cdiv(p.N, 256), rounds = m2f_cdiv(t256, 256);
+        const bool small8 = (size_t)p.M * p.a.ldq[0] * 2 < 0x80000000ull && (size_t)p.N * p.b.ldq[0] * 2 < 0x80000000ull;
+        if (p8_on && small8 && t256 >= p8_min && t256 * 100 >= 85 * rounds * 256 && !(p.a.k[0] & 63) && (!p.c8 || (p.ldc & 7) == 0))
+            return m2f_p8_launch_kc_fp8(gb, stream);
+    }
     {   // the ring form (gemm_ring_256x128_fp8.hip) from one chip-filling round of 256x128 tiles on; M2F_RING_FP8=0 keeps the register-staged build
         static const int ring8 = getenv("M2F_RING_FP8") ? atoi(getenv("M2F_RING_FP8")) : 1;
         const bool small = (size_t)p.M * p.a.ldq[0] * 2 < 0x80000000ull && (size_t)p.N * p.b.ldq[0] * 2 < 0x80000000ull;

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
     // staging ring - so pieces issued past the tile's last k-tile (the schedule keeps issuing them: the counted waits count them) are
     // range-checked to zeros AND redirected into a 2 KiB dump area behind the operand buffers (the wave's W^T image, unused until then)
     constexpr bool PER_TILE = EPI == 3;
+    constexpr bool FWD = EPI == 2 || EPI == 4;          // forward-form epilogue (bias / activation / residual); 4: OCP e4m3 operands (see quad)
     unsigned s_dump = 0;                                           // 0 = normal destinations
     unsigned s_kA = 0, s_kB = 0, s_stepA = 0, s_stepB = 0, s_halfA = 0, s_halfB = 0, vA[2], vB[2];
     ring_u32x4 ra, rb;
@@ -351,17 +352,36 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
         // epilogue fields before the k-loop (scalar loads from a cold line cost the tile its MFMA pipe when read after it)
         float* __restrict__ Cp = P.c;
         const int ldc = P.ldc, Mm = H.M, Nn = H.N;
-        const float* __restrict__ bias = EPI == 2 ? P.bias : nullptr;
-        const float* __restrict__ res = EPI == 2 ? P.res : nullptr;
+        const float* __restrict__ bias = FWD ? P.bias : nullptr;
+        const float* __restrict__ res = FWD ? P.res : nullptr;
         const int ldres = P.ldres;
-        uint16_t* __restrict__ C16 = EPI == 2 && !(P.flags & GF_NO_BF16) ? reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c)) : nullptr;
-        const bool relu_out = P.flags & GF_RELU_OUT, gelu = P.flags & GF_GELU_OUT, no32 = EPI == 2 && (P.flags & GF_NO_F32) && C16;
+        uint16_t* __restrict__ C16 = FWD && !(P.flags & GF_NO_BF16) ? reinterpret_cast<uint16_t*>(m2f_shadow_of(gb.sh, P.c)) : nullptr;
+        const bool relu_out = P.flags & GF_RELU_OUT, gelu = P.flags & GF_GELU_OUT, no32 = FWD && (P.flags & GF_NO_F32) && C16;
+        // EPI 4: the accumulator is de-quantised first (1 / (scale_a scale_b)); c8 set: the result leaves as e4m3(x * c8_scale) INSTEAD of fp32 / bf16
+        const float acc_scale = EPI == 4 ? P.acc_scale : 1.f, c8_scale = EPI == 4 ? P.c8_scale : 1.f;
+        uint8_t* __restrict__ C8 = EPI == 4 ? P.c8 : nullptr;
         // EPI 1, `res` set: the weight gradient leaves as bf16 INSTEAD of fp32, at the same element index of a bf16 gradient buffer (the
         // data-parallel bf16 exchange sends that buffer as it is: no fp32 dW round trip, no rounding pass; m2f_plan_grad_bf16)
         uint16_t* __restrict__ G16 = EPI == 1 ? reinterpret_cast<uint16_t*>(const_cast<float*>(P.res)) : nullptr;
 
         auto quad = [&](auto a_tag, auto b_tag, const bf16x8 (&bb)[2][2]) {
             constexpr int AH = decltype(a_tag)::value, BH = decltype(b_tag)::value;
+            if constexpr (EPI == 4) {
+                // OCP e4m3 operands: the same bytes through the same LDS image - a 128-byte row holds 128 k-values, the lane's two 16-byte reads of a
+                // row ARE the 32-byte operand of v_mfma_scale_f32_16x16x128_f8f6f4 (scale operands 0 = unscaled; 2x the bf16 rate).  Which 32 of the
+                // 128 k-values a lane group supplies does not matter as long as A and B agree - and both come from the same chunk positions.
+                typedef int p8_v8i __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const ring_u32x4 a0 = __builtin_bit_cast(ring_u32x4, af[i][0]), a1 = __builtin_bit_cast(ring_u32x4, af[i][1]);
+                        const ring_u32x4 b0 = __builtin_bit_cast(ring_u32x4, bb[j][0]), b1 = __builtin_bit_cast(ring_u32x4, bb[j][1]);
+                        const p8_v8i fa = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+                        const p8_v8i fb = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+                        acc[AH][BH][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa, acc[AH][BH][i][j], 0, 0, 0, 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -369,6 +389,7 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)         // operands swapped: the lane then holds 4 consecutive COLUMNS of row lr (16-byte stores)
                         acc[AH][BH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[j][s], af[i][s], acc[AH][BH][i][j], 0, 0, 0);
+            }
         };
         auto bias_sums = [&](int ah) {                  // bias gradient = sum over k of A's rows (before any ReLU on A)
 #pragma unroll
@@ -646,11 +667,12 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                          (!res || (((ldres & 3) == 0) && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (!C16 || (((ldc & 7) == 0) && (reinterpret_cast<uintptr_t>(C16) & 15) == 0));
-        const bool whole = vec && m0 + C::BM <= Mm && n0 + C::BN <= Nn;               // block-uniform
+        bool whole = vec && m0 + C::BM <= Mm && n0 + C::BN <= Nn;                     // block-uniform
+        if constexpr (EPI == 4) whole = whole && (!C8 || (((ldc & 7) == 0) && (reinterpret_cast<uintptr_t>(C8) & 7) == 0));       // (8-byte e4m3 stores)
         // one 16-row x 16-column block of the wave: lane -> row lr, columns 4 g .. 4 g + 3
         auto element = [&](float a, float bv, float rv) {                              // the element order of ring_epilogue
-            if constexpr (EPI != 2) return a;
-            float x = a + bv;
+            if constexpr (!FWD) return a;
+            float x = (EPI == 4 ? a * acc_scale : a) + bv;
             x = relu_out ? fmaxf(x, 0.f) : x;
             if (gelu) x = m2f_gelu<true>(x);
             return x + rv;
@@ -668,12 +690,12 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
             //   bf16: v_permlane32_swap + v_permlane16_swap of the packed pairs leave lane group q with columns 8 q .. 8 q + 7 of row lr.
             // The residual (EPI 2) is added in place BEFORE the first store, in batches of eight loads: loads and stores share one in-order
             // counter, and a load issued behind stores waits for them (24k cycles per tile with the loads between the stores, 12k without).
-            const bool has16 = (EPI == 2 && C16) || (EPI == 1 && G16);
-            const bool has32 = !(no32 || (EPI == 1 && G16));
-            const int n_st = (has32 ? 32 : 0) + (has16 ? 16 : 0);
+            const bool has16 = ((FWD && C16) || (EPI == 1 && G16)) && !C8;
+            const bool has32 = !(no32 || (EPI == 1 && G16) || C8);
+            const int n_st = (has32 ? 32 : 0) + (has16 ? 16 : 0) + (C8 ? 16 : 0);
             ep_relax = n_st;
-            if constexpr (EPI == 2) {
-                if (bias || relu_out || gelu) {
+            if constexpr (FWD) {
+                if (bias || relu_out || gelu || EPI == 4) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -747,6 +769,15 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                             ring_u32x4 w = {a0, a1, b0, b1};                    // lane group q: columns 8 q .. 8 q + 3 | 8 q + 4 .. 8 q + 7 of row lr
                             *reinterpret_cast<ring_u32x4*>(O16 + (size_t)((uint32_t)((rowb + lr) * ldc + colb + 8 * g))) = w;
                         }
+                        if constexpr (EPI == 4) {
+                            if (C8) {                                           // e4m3 result: 8 bytes per lane after the same exchange
+                                uint32_t a0 = m2f_fp8x4_bits(x0[0] * c8_scale, x0[1] * c8_scale, x0[2] * c8_scale, x0[3] * c8_scale);
+                                uint32_t b0 = m2f_fp8x4_bits(x1[0] * c8_scale, x1[1] * c8_scale, x1[2] * c8_scale, x1[3] * c8_scale);
+                                p8_swap2(a0, b0);
+                                uint2 w8; w8.x = a0; w8.y = b0;
+                                *reinterpret_cast<uint2*>(C8 + (size_t)((uint32_t)((rowb + lr) * ldc + colb + 8 * g))) = w8;
+                            }
+                        }
                     }
         } else {
             // edge tiles / unaligned results: element by element, masked (rare: 300-wide audio features, the [7, d] classifier weight)
@@ -765,15 +796,16 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
                                 const bool in = row < Mm && col + e < Nn;
                                 const size_t oc = (size_t)((uint32_t)(row * ldc + col + e));
                                 float bvv = 0.f, rvv = 0.f;
-                                if constexpr (EPI == 2) {
+                                if constexpr (FWD) {
                                     if (bias && in) bvv = bias[col + e];
                                     if (res && in) rvv = res[(size_t)((uint32_t)(row * ldres + col + e))];
                                 }
                                 const float x = element(v[e], bvv, rvv);
                                 if (in && EPI == 1 && G16) G16[oc] = m2f_bf16_bits(x);
+                                else if (in && C8) C8[oc] = (uint8_t)(m2f_fp8x4_bits(x * c8_scale, 0.f, 0.f, 0.f) & 0xffu);
                                 else if (in) {
                                     Cp[oc] = x;                         // (edge tiles keep the fp32 store whatever GF_NO_F32 says, as the ring form does)
-                                    if constexpr (EPI == 2) { if (C16) C16[oc] = m2f_bf16_bits(x); }
+                                    if constexpr (FWD) { if (C16) C16[oc] = m2f_bf16_bits(x); }
                                 }
                             }
                         }

@@ -28,6 +28,13 @@ hipError_t m2f_p8_launch_kc(GemmBatch& gb, hipStream_t stream) {
     return launch_p8_grouped<false, 2>(gb, stream);
 }
 
+// the text encoder's fp8 launches (OCP e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4; k and the leading dimensions arrive in byte PAIRS -
+// the staging code moves 16-byte chunks of a row whatever they hold): de-quantising epilogue, fp32 / bf16 / e4m3 result
+hipError_t m2f_p8_launch_kc_fp8(GemmBatch& gb, hipStream_t stream) {
+    gb.p8_skew = p8_skew_env();
+    return launch_p8_grouped<false, 4>(gb, stream);
+}
+
 // the table launch with the optimizer in its epilogue (gb.adam set; every problem carries its shadow pointers in res / gate)
 hipError_t m2f_p8_launch_table_rc_adam(const GemmBatch& gb, hipStream_t stream) {
     if (!gb.adam) return hipErrorInvalidValue;

@@ -131,6 +131,7 @@ hipError_t m2f_launch_gemm_ring_table(const GemmBatch& gb, hipStream_t stream);
 // eight-phase 256x256 form (gemm_p8.h): forward-form launches with the 256x128 ring form's epilogue set, single segment, k % 64 == 0
 bool m2f_gemm_p8_ok(const GemmBatch& gb);
 hipError_t m2f_p8_launch_kc(GemmBatch& gb, hipStream_t stream);
+hipError_t m2f_p8_launch_kc_fp8(GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_p8_launch_table_rc(const GemmBatch& gb, hipStream_t stream);
 hipError_t m2f_p8_launch_table_rc_adam(const GemmBatch& gb, hipStream_t stream);     // Adam in the epilogue (gb.adam)
 

@@ -110,8 +110,10 @@ def test_gemm_large_m_tile_and_gelu_epilogue():
     _close(got32, 0.5 * pre32 * (1.0 + torch.erf(pre32 / 2.0 ** 0.5)), 1e-5, "fp32 GEMM + GELU")
 
 
-# (the last two take the ring form, gemm_ring_256x128_fp8.hip: edge tiles + a k remainder, and whole tiles incl. the e4m3 result)
-@pytest.mark.parametrize("shape", [(300, 200, 64), (1024, 768, 768), (4096 * 9 + 5, 1024 + 40, 256 + 48), (8192, 1024, 512)])
+# (shapes 3 and 4 take the ring form, gemm_ring_256x128_fp8.hip: edge tiles + a k remainder, and whole tiles incl. the e4m3 result; the last three the
+#  eight-phase form, gemm_p8.h EPI 4 on v_mfma_scale_f32_16x16x128_f8f6f4: 256 tiles of 256x256 = one round, whole tiles, an edge row of tiles, a long k)
+@pytest.mark.parametrize("shape", [(300, 200, 64), (1024, 768, 768), (4096 * 9 + 5, 1024 + 40, 256 + 48), (8192, 1024, 512),
+                                   (4096, 4096, 256), (4000, 4096, 384), (16384, 1024, 1024)])
 def test_gemm_fp8_matches_dequantised_reference(shape):
     """fp8 (OCP e4m3) operands, fp32 accumulate: exact against an fp32 product of the SAME quantised values (the MFMA
     multiplies e4m3 x e4m3 exactly and accumulates in fp32), with the de-quantisation scale, bias, GELU and residual."""

@@ -75,10 +75,12 @@ def test_bench_plan_fp32_matches_oracle(workload):
         assert float((g - r).abs().max()) <= 0.1 * float(r.abs().max()) + 2e-7, (k, float((g - r).abs().max()), float(r.abs().max()))
 
 
-# bf16-mode gradient direction per tensor against the fp32 oracle (measured worst over all tensors, round 4: see the asserts' messages
-# when they fail): cosine >= 0.99 everywhere; the +-1 probe digest within this fraction of the tensor's gradient norm
-COS_MIN = {"c2": 0.99, "c3": 0.99, "c2p": 0.99}
-DIGEST_MAX = {"c2": 0.25, "c3": 0.25, "c2p": 0.25}
+# bf16-mode gradient DIRECTION per tensor against the fp32 oracle: cosine of the whole tensor, and the +-1 probe digest as a fraction of the tensor's
+# gradient norm.  Measured on MI355X (round 4, printed by the test with -s): worst cosine over all tensors 0.99752 (c2) / 0.99715 (c3) / 0.99768 (c2p) - always a first FFN
+# layer of the audio encoder, whose ReLU gates flip under bf16 operands; worst digest 0.155 / 0.136 / 0.129 (a +-1 probe of the difference: ~2 sigma of
+# sqrt(2 (1 - cos)) = 0.075).  Bounds = the measured values with a margin for other seeds / boxes, far inside what a wrong kernel produces (cos < 0.9).
+COS_MIN = {"c2": 0.995, "c3": 0.995, "c2p": 0.995}
+DIGEST_MAX = {"c2": 0.22, "c3": 0.22, "c2p": 0.22}
 
 
 @pytest.mark.parametrize("workload", ["c2", "c3", "c2p"])
@@ -115,6 +117,7 @@ def test_bench_plan_bf16_within_stated_tolerance(workload):
             worst_dig = max(worst_dig, (dig, k))
             checked += 1
     assert checked >= 60, checked
+    print(f"{workload} bf16 gradients vs oracle over {checked} tensors: worst cosine {worst_cos[0]:.5f} ({worst_cos[1]}), worst digest {worst_dig[0]:.4f} ({worst_dig[1]})")
     assert worst_cos[0] >= COS_MIN[workload], worst_cos
     assert worst_dig[0] <= DIGEST_MAX[workload], worst_dig
 

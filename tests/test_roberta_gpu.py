@@ -124,13 +124,15 @@ def test_fp8_text_encoder_cost_in_downstream_logits():
         d = float((logits[prec] - ref)[valid].abs().max())
         agree = float((logits[prec].argmax(-1) == ref.argmax(-1))[valid].float().mean())
         stats[prec] = (d, agree)
-    # measured (round 4): see the message; bounds stated here
+    print(f"downstream logits vs the fp32 encoder (spread of a row's logits {spread:.3f}): bf16 max |d| {stats['bf16'][0]:.4f}, argmax agreement {stats['bf16'][1]:.3f}; fp8 {stats['fp8'][0]:.4f}, {stats['fp8'][1]:.3f}")
     assert stats["bf16"][0] < FP8_LOGIT_BOUNDS["bf16"] and stats["bf16"][1] >= 0.97, (stats, spread)
     assert stats["fp8"][0] < FP8_LOGIT_BOUNDS["fp8"] and stats["fp8"][1] >= 0.90, (stats, spread)
     assert stats["fp8"][0] >= stats["bf16"][0] * 0.5, stats               # fp8 is the coarser mode: the numbers must say so
 
 
-FP8_LOGIT_BOUNDS = {"bf16": 5e-2, "fp8": 0.3}
+# measured on MI355X (round 4): a row's logits spread 0.31; bf16 encoder max |dlogit| 2e-4, fp8 encoder 2.8e-3, argmax agreement 1.000 / 1.000 on the 128
+# valid utterances.  Bounds: an order of magnitude above the measurement, two below the spread.
+FP8_LOGIT_BOUNDS = {"bf16": 2e-3, "fp8": 2e-2}
 
 
 # ---- round 4: the attention kernel of the encoder's bf16 mode (csrc/attention_long.hip) against an fp32 softmax(QK^T)V of the SAME

@@ -229,6 +229,11 @@ int m2f_attention_long_fwd_bf16_out8(int B, int S, int H, int hd, const uint16_t
                                      const uint16_t* v, int ldv, const uint8_t* key_pad, uint16_t* out16, float* out32, uint8_t* out8,
                                      float out8_scale, int ldo, m2f_stream_t stream);
 
+/* Diagnostic (tools/ln_stats_ab.py): one LayerNorm-forward launch over 1..4 problems of T rows, as the plans merge them; pre = 1 reads
+ * (mean, rstd) from `stats` instead of computing them - the cost of a LayerNorm whose statistics came out of the preceding GEMM's epilogue. */
+int m2f_layernorm_fwd_diag(int T, int n_prob, const int* d, const float* const* x, const float* const* gamma, const float* const* beta, float* const* out,
+                           float* const* stats, float eps, int pre, m2f_stream_t stream);
+
 /* m2f_layernorm_fwd that ALSO writes its result as e4m3(value * out8_scale), saturating, into out8 [T, d] (d % 4 == 0): the fp8 text
  * encoder's LayerNorm outputs are GEMM operands (round 4: replaces a quantise pass over the fp32 result). */
 int m2f_layernorm_fwd_out8(int T, int d, const float* x, const float* gamma, const float* beta, const float* res, float* out,

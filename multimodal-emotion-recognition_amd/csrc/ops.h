@@ -235,6 +235,8 @@ struct LnBatch {
     float eps;
     const uint32_t* rng; uint32_t drop_thresh; float drop_scale;
     ShadowMap sh;                      // out (fwd) / dx, dx_masked (bwd) also written as bf16
+    int pre_stats;                     // forward, diagnostic (tools/ln_stats_ab.py): 1 = mean / rstd are READ from `stats` instead of computed (what a LayerNorm
+                                       // whose statistics came out of the preceding GEMM's epilogue would cost)
     uint8_t* out8; float out8_scale;   // forward, problem 0 only (nullable): out ALSO as OCP e4m3 bytes of value * out8_scale, saturating, row stride d
                                        // (the operand the text encoder's fp8 GEMMs stage: no quantise pass; d % 4 == 0)
 };

@@ -2173,6 +2173,22 @@ int m2f_layernorm_fwd(int T, int d, const float* x, const float* gamma, const fl
     return 0;
 }
 
+/* diagnostic (tools/ln_stats_ab.py; not in include/m2fnet_hip.h's product surface): the LayerNorm forward over `count` problems merged in one launch
+ * as the plans do (x / out of problem i at x + i * T * ld ... the caller lays them out), statistics computed (pre = 0) or read from `stats` (pre = 1) */
+int m2f_layernorm_fwd_diag(int T, int n_prob, const int* d, const float* const* x, const float* const* gamma, const float* const* beta, float* const* out,
+                           float* const* stats, float eps, int pre, m2f_stream_t stream) {
+    if (n_prob < 1 || n_prob > M2F_LN_MAX_PROBLEMS) return fail("m2f_layernorm_fwd_diag: 1..4 problems");
+    LnBatch lb;
+    memset(&lb, 0, sizeof(lb));
+    for (int i = 0; i < n_prob; ++i) {
+        LnProblem& p = lb.pr[i];
+        p.x = x[i]; p.gamma = gamma[i]; p.beta = beta[i]; p.out = out[i]; p.stats = stats[i]; p.d = d[i];
+    }
+    lb.count = n_prob; lb.T = T; lb.eps = eps; lb.drop_scale = 1.f; lb.sh = g_sh; lb.pre_stats = pre;
+    M2F_HIP(m2f_launch_ln_fwd(lb, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int m2f_layernorm_fwd_out8(int T, int d, const float* x, const float* gamma, const float* beta, const float* res, float* out,
                            float* stats, float eps, uint8_t* out8, float out8_scale, m2f_stream_t stream) {
     if (!out8 || (d & 3) || (reinterpret_cast<uintptr_t>(out8) & 3)) return fail("m2f_layernorm_fwd_out8: e4m3 output needs d % 4 == 0 and a 4-byte aligned buffer");

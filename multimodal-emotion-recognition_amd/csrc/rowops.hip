@@ -102,20 +102,25 @@ __global__ __launch_bounds__(256) void m2f_ln_fwd_kernel(const LnBatch lb) {
         if (row >= lb.T) break;                             // wave-uniform
         RowRegs<NV> x;
         row_load(x, P.x + (size_t)row * ld, d, vec, lane);
-        float s = 0.f;
+        float mean, rstd;
+        if (lb.pre_stats) {                                 // (diagnostic: statistics from memory, no reductions - block-uniform branch)
+            mean = P.stats[2 * row]; rstd = P.stats[2 * row + 1];
+        } else {
+            float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) s += (x.v[j][0] + x.v[j][1]) + (x.v[j][2] + x.v[j][3]);
-        const float mean = m2f_wave_sum(s) * invd;
-        float q = 0.f;
+            for (int j = 0; j < NV; ++j) s += (x.v[j][0] + x.v[j][1]) + (x.v[j][2] + x.v[j][3]);
+            mean = m2f_wave_sum(s) * invd;
+            float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
+            for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 4 * (lane + 64 * j) + e;
-                const float t = (c < d) ? x.v[j][e] - mean : 0.f;
-                q += t * t;
-            }
-        const float rstd = 1.0f / sqrtf(m2f_wave_sum(q) * invd + lb.eps);
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * (lane + 64 * j) + e;
+                    const float t = (c < d) ? x.v[j][e] - mean : 0.f;
+                    q += t * t;
+                }
+            rstd = 1.0f / sqrtf(m2f_wave_sum(q) * invd + lb.eps);
+        }
         RowRegs<NV> res;
         if (P.res) row_load(res, P.res + (size_t)row * ld, d, vec, lane);
 #pragma unroll

@@ -122,6 +122,7 @@ SIGNATURES = {
                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "m2f_layernorm_fwd_out8": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float,
                                        c_void_p]),
+    "m2f_layernorm_fwd_diag": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "m2f_set_shadow_only": (c_int, [c_int]),
     "m2f_attention_long_fwd": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p, c_int, c_void_p]),

@@ -33,6 +33,8 @@ else
   M2F_ROBERTA_FAT=1 python3 tools/bench_text_encoder.py --model large --dtype fp8 > $O/f4_text_encoder_large_fp8_round3_dataflow.json 2>> $O/err.txt
   for m in bf16 fp8; do tools/kstats_cmd.sh ${tag}_f4_$m tools/bench_text_encoder.py --model large --dtype $m > $O/f4_text_encoder_large_kernel_stats_$m.txt 2>&1; done
   python3 tools/bench_text_encoder.py --model large --utterances 1024 --with-fusion-step > $O/f4_c5_dataflow_large_bf16.json 2>> $O/err.txt
+  python3 tools/bench_text_encoder.py --model large --utterances 1024 --with-fusion-step --dtype fp8 > $O/f4_c5_dataflow_large_fp8.json 2>> $O/err.txt
+  python3 tools/ln_stats_ab.py 2>&1 | grep -v amdgpu.ids > $O/ln_stats_ab.txt
   python3 tools/p8_bench.py bench 20 2>&1 | grep -v amdgpu.ids > $O/p8_kernel_bench.txt
   tools/store_probe/store_probe 4096 > $O/store_shape_probe.txt 2>&1
   python3 tools/chain_floor.py c3 2>&1 | grep -v amdgpu.ids > $O/chain_gemm_floor_c3.txt

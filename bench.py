@@ -371,7 +371,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         out["comm"] = comm
     if roofline:
         out["roofline"] = {
-            "bound": "mfma", "kernel": "m2f_gemm16_ring_kernel (bf16: forward / input-gradient launches as 128x128, 128x64 or 64x64 ring tiles; the weight-gradient table launch in its row-major form) or m2f_gemm_kernel (fp32): grouped MFMA GEMM launches of one step",
+            "bound": "mfma", "kernel": "bf16: m2f_gemm16_ring_kernel (forward / input-gradient launches as 256x128, 128x128, 128x64 or 64x64 ring tiles) + m2f_gemm_p8_kernel (the weight-gradient table launch, 256x256 tiles on the eight-phase schedule); fp32: m2f_gemm_kernel - the grouped MFMA GEMM launches of one step",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None if traffic is None or traffic["_stale"] else float(traffic["traffic_bytes_per_launch"]),
             "traffic_source": None if traffic is None else {"file": traffic["_source"], "stale": traffic["_stale"]},

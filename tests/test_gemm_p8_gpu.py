@@ -62,3 +62,47 @@ def test_large_forward_launches_reach_the_eight_phase_kernel_through_the_dispatc
     ref = torch.nn.functional.gelu(ar @ br.t() + bias.double()) + res.double()
     err = (c.double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 4e-3, err
+
+
+@pytest.mark.parametrize("M", [8192, 8192 - 100])
+def test_bf16_shadow_and_shadow_only_results_of_the_eight_phase_kernel(M):
+    """What the text encoder's bf16 data flow relies on (round 4): a result inside the shadow map also leaves as bf16 - sixteen bytes per lane after the
+    permlane exchange of gemm_p8.h's epilogue - bit for bit the rounding of the fp32 result; with m2f_set_shadow_only(1) ONLY the bf16 copy is written
+    (whole tiles: the fp32 buffer keeps its sentinel; edge tiles still write both).  M = 8,092: the last row of tiles takes the element-wise edge path."""
+    import torch
+    import mer_amd  # noqa: F401
+    from mer_amd import functional as F, runtime
+    lib = runtime.lib()
+    g = torch.Generator().manual_seed(9)
+    N, K = 2048, 512
+    a = (torch.randn(M, K, generator=g) * 0.5).cuda()
+    b = (torch.randn(N, K, generator=g) * 0.5 + 0.05).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ws = torch.full((M * N,), float("nan"), device="cuda")
+    sh = torch.zeros(M * N, dtype=torch.bfloat16, device="cuda")
+    out = ws.view(M, N)
+    runtime.check(lib.m2f_set_shadow_map(ws.data_ptr(), sh.data_ptr(), ws.numel()), "m2f_set_shadow_map")
+    try:
+        before = lib.m2f_gemm_ring_launches()
+        F.gemm(a, b, layout=F.NT, precision=runtime.BF16, bias=bias, relu_out=2, src16=True, out=out)
+        torch.cuda.synchronize()
+        assert lib.m2f_gemm_ring_launches() == before + 1
+        ar, br = a.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
+        ref = torch.nn.functional.gelu(ar @ br.t() + bias.double())
+        assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 4e-3
+        assert torch.equal(sh.view(M, N), out.to(torch.bfloat16))                 # the shadow IS the rounded fp32 result
+        both = sh.clone()
+        ws.fill_(float("nan")); sh.zero_()
+        runtime.check(lib.m2f_set_shadow_only(1), "m2f_set_shadow_only")
+        try:
+            F.gemm(a, b, layout=F.NT, precision=runtime.BF16, bias=bias, relu_out=2, src16=True, out=out)
+        finally:
+            runtime.check(lib.m2f_set_shadow_only(0), "m2f_set_shadow_only")
+        torch.cuda.synchronize()
+        assert torch.equal(sh, both)                                              # same bits with or without the fp32 store
+        whole_rows = M // 256 * 256
+        assert torch.isnan(out[:whole_rows]).all()                                # whole tiles: the fp32 buffer was not touched
+        if whole_rows < M:
+            assert torch.equal(out[whole_rows:].to(torch.bfloat16), sh.view(M, N)[whole_rows:])      # edge tiles keep the fp32 store
+    finally:
+        runtime.check(lib.m2f_set_shadow_map(None, None, 0), "m2f_set_shadow_map")

@@ -238,3 +238,26 @@ def test_e4m3_outputs_of_attention_and_layernorm_equal_a_quantise_pass_over_thei
     assert (y - ref).abs().max().item() < 1e-3
     assert torch.equal(y8, F.quantize_fp8(y, 16.0).view(torch.uint8))
     assert (y.abs() * 16.0 > 448).any()                               # (the saturating branch is exercised)
+
+
+def test_encoder_at_dispatch_scale_bf16_and_fp8_track_the_fp32_mode():
+    """RoBERTa-large layer geometry (hidden 1,024, 16 heads, FFN 4,096), 2 layers, 192 sequences x 64 tokens = 12,288 token rows: the size at which the
+    packed projection and the FFN launches reach the eight-phase 256 x 256 kernels (gemm_p8.h EPI 2 / EPI 4: 576 / 768 tiles), with bf16-only / e4m3-only
+    operand copies and the bf16 attention kernel - against the fp32 mode of the same encoder on the same weights and tokens (the mode the fixtures and the
+    oracle pin at small sizes).  Bounds of the small cases, except the fp8 maximum: over 12.6 M hidden values the tail of the e4m3 rounding noise reaches further
+    than over the ~10^4 of the fixtures (measured: bf16 mean 0.0045 / max 0.034 / worst row cosine 0.99997; fp8 mean 0.070 / max 0.60 / 0.9936)."""
+    c = SR.cfg(1024, 2, 16, 4096, 400, 80)
+    B, S = 192, 64
+    g = np.random.Generator(np.random.Philox(key=77))
+    lengths = [int(x) for x in g.integers(8, S + 1, size=B)]
+    ids, mask = SR.make_batch(c, B, S, lengths, seed=78)
+    ref = _enc(c, "fp32")(ids.cuda(), mask.cuda()).cpu()
+    valid = mask.bool()
+    for prec, mean_max, abs_max in (("bf16", 1e-2, 6e-2), ("fp8", 0.1, 1.0)):
+        got = _enc(c, prec)(ids.cuda(), mask.cuda()).cpu()
+        d = (got - ref)[valid]
+        cos = torch.nn.functional.cosine_similarity(got[valid], ref[valid], dim=-1).min().item()
+        print(f"{prec} encoder at 12,288 rows vs fp32 mode: mean |d| {d.abs().mean():.4f}, max |d| {d.abs().max():.4f}, worst row cosine {cos:.5f}")
+        assert torch.isfinite(got[valid]).all()
+        assert d.abs().mean().item() < mean_max and d.abs().max().item() < abs_max, (prec, d.abs().mean().item(), d.abs().max().item())
+        assert cos > 0.99, (prec, cos)

@@ -216,6 +216,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
         if world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
+        shadows_fresh_after_loop = bool(eng.shadows_fresh())          # (N > 1: the bucket-wise optimizer launches write the shadows too)
         elapsed = dp.reduce_metrics([elapsed], device=device)[0]
         loss = float(stepper.reducer.global_loss().item())
         plan.check_status()
@@ -352,7 +353,7 @@ def run_workload(wl, dtype, rank, world, device, steps, warmup, use_graph, ragge
                    "dropout": c.dropout, "parallelism": f"dp{world}", "hipgraph": use_graph,
                    "launches_per_step": plan.num_launches(),
                    "token_rows": plan.T, "plan_shape": [plan.B, plan.L], "packed": bool(plan.packed),
-                   "param_shadows": "written by the fused Adam kernel (no parameter casts in the forward)" if eng.wshadow is not None and world == 1
+                   "param_shadows": "written by the fused Adam kernel (no parameter casts in the forward)" if eng.wshadow is not None and shadows_fresh_after_loop
                                     else ("re-cast at the head of every forward" if dtype == "bf16" else None),
                    "source_hash": source_hash()},
         "loss": loss,

@@ -56,7 +56,8 @@ __device__ __forceinline__ bf16x8 p8_floor8(bf16x8 f, uint32_t floor2) {
 // four times per k-tile.  Hidden in asm, the pieces are ordered against the fragment reads by the kernel's own counted vmcnt + barriers
 // (header comment); M0 is written in the statement that uses it (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void p8_dma16(const ring_u32x4& rsrc, unsigned lds, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rsrc) : "memory");
+    // (one wait state between the write of M0 and the LDS-DMA instruction that reads it: s_nop 0; s_nop 4 cost 3-6 % at K >= 4,096)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rsrc) : "memory");
 }
 // raw buffer descriptor (stride 0, range-checked against `bytes`), all words provably uniform
 __device__ __forceinline__ ring_u32x4 p8_rsrc(const void* q, unsigned bytes) {
@@ -443,6 +444,8 @@ __global__ __launch_bounds__(512) void m2f_gemm_p8_kernel(const GemmBatch gb) {
             P8_STAMP(ts3);
             P8_ACC(0);
             // ---- phase 2: B part 1 (4 reads); stage B0 of k-tile + 2 (this buffer) ----
+            // (measured in round 4: these four reads issued under phase 1's MFMAs instead - same results, row-major 4,096^3 1,137 -> 1,058 TFLOP/s, k-contiguous
+            //  8,192^3 1,255 -> 1,228: transposing reads between MFMAs cost more than they hide)
             P8_STAMP(ts0);
             read_b(xo, 1, bf1);
             stage(I2{}, x);
